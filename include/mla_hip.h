@@ -1,0 +1,124 @@
+/*
+ * mla_hip.h -- C ABI of libmla_hip.so: the MI355X (gfx950) kernels of the MLA
+ * alternating-unimodal training step (reference: main.py:419-476 and the modules it calls).
+ *
+ * The reference has no FFI: its "operator interface" for this path is the set of implicit ATen ops
+ * that nn.Conv2d / nn.BatchNorm2d / nn.MaxPool2d / F.adaptive_avg_pool / nn.Linear /
+ * nn.CrossEntropyLoss / GSPlugin.before_update / torch.optim.SGD trigger.  Each entry point below
+ * replaces one of those op groups and cites the reference line that triggers it.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch types; nothing is allocated, freed or synchronised;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); kernels are enqueued on it;
+ *   - activations are NHWC fp32 ("pixel-major": [N][H][W][C]); conv weights are HWIO fp32
+ *     ([KH][KW][Cin][Cout]); the Python boundary converts from/to the reference's NCHW / OIHW;
+ *   - return 0 on success, a negative mla_status on error (never throws, never aborts).
+ */
+#ifndef MLA_HIP_H
+#define MLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum mla_status {
+  MLA_OK = 0,
+  MLA_ERR_INVALID_ARG = -1,   /* shape/pointer the kernels do not support */
+  MLA_ERR_WORKSPACE = -2,     /* workspace too small */
+  MLA_ERR_LAUNCH = -3         /* hipGetLastError() != hipSuccess after launch */
+};
+
+/* Library/ABI version and a human-readable description of the last error on this thread. */
+int mla_abi_version(void);
+const char* mla_last_error(void);
+
+/* ---- layout (boundary) ---------------------------------------------------------------------- */
+/* (B,C,T,H,W) video -> (B*T,H,W,C) frames.  Replaces backbone.py:144-147 permute+contiguous+view. */
+int mla_video_to_nhwc(const float* src, float* dst, int B, int C, int T, int H, int W, void* stream);
+/* generic NCHW <-> NHWC (tests / state import) */
+int mla_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+int mla_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+
+/* ---- convolution: nn.Conv2d (backbone.py:4-12, 79-83, 28, 31, 127) --------------------------- */
+/* Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * bn_partial (nullable): if given, the epilogue also writes per-M-tile column sums and sums of
+ * squares of y, layout [tiles][2][Cout]; *bn_tiles receives `tiles`.  Feed to mla_bn_finalize. */
+size_t mla_conv2d_fwd_partial_elems(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int mla_conv2d_fwd(const float* x, const float* w_hwio, float* y,
+                   int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                   float* bn_partial, int* bn_tiles, void* stream);
+
+/* Input gradient (autograd of the above).  dx = dgrad(dy) [+ residual] [* (relu_src > 0)].
+ * `residual` may alias `dx` (accumulate).  wt_ws: Cin*Cout*KH*KW floats of scratch (per-tap
+ * transposed weights).  (H,W) are the INPUT dims of the forward conv. */
+int mla_conv2d_dgrad(const float* dy, const float* w_hwio, float* dx,
+                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                     const float* residual, const float* relu_src, float* wt_ws, void* stream);
+
+/* Weight gradient: dw_hwio[kh][kw][ci][co] = sum_pixels x * dy.  Deterministic split-K:
+ * partial slabs in `ws` (mla_conv2d_wgrad_ws_bytes) followed by an ordered reduce. */
+size_t mla_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int mla_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio,
+                     int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- BatchNorm2d, training mode (backbone.py:29, 32, 86, 128) -------------------------------- */
+/* x is [M][C] (M = N*H*W).  Statistics: either mla_bn_stats (reads x) or conv-fused partials. */
+size_t mla_bn_stats_partial_elems(int M, int C);
+int mla_bn_stats_partial(const float* x, int M, int C, float* partial, int* tiles, void* stream);
+/* Reduce partials in fp64 -> mean, invstd (biased var, eps), running stats (unbiased var, momentum). */
+int mla_bn_finalize(const float* partial, int tiles, int M, int C, float eps, float momentum,
+                    float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
+/* out = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+int mla_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                 const float* beta, const float* residual, float* out, int M, int C, int relu, void* stream);
+/* Backward.  g = dout * (relu_out > 0) if relu_out else dout;
+ * dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/M - xhat*dgamma/M).
+ * g_out (nullable) receives g (the gradient of the residual branch).  ws: mla_bn_bwd_ws_elems floats. */
+size_t mla_bn_bwd_ws_elems(int M, int C);
+int mla_bn_bwd(const float* dout, const float* relu_out, const float* x, const float* mean,
+               const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+               float* g_out, float* ws, int M, int C, void* stream);
+
+/* ---- pooling ---------------------------------------------------------------------------------- */
+/* nn.MaxPool2d(3,2,1) (backbone.py:88,152); idx = window position 0..8 of the first maximum. */
+int mla_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+/* dx = scatter(dy) [* (relu_src > 0)] */
+int mla_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, const float* relu_src, float* dx,
+                         int N, int H, int W, int C, void* stream);
+/* adaptive_avg_pool2d/3d(.,1)+flatten (basic_model.py:56-65): x [NB][P][C] -> y [NB][C] */
+int mla_avgpool_fwd(const float* x, float* y, int NB, int P, int C, void* stream);
+/* dx[nb][p][c] = dy[nb][c]/P [* (relu_src > 0)]  (relu_src: the pooled tensor, output of the last ReLU) */
+int mla_avgpool_bwd(const float* dy, const float* relu_src, float* dx, int NB, int P, int C, void* stream);
+
+/* ---- shared head + cross entropy (fusion_modules.py:19; main.py:130, 432-435, 444-447) ------- */
+/* logits = X W^T + b; loss = -sum_i log softmax(logits_i)[label_i] * inv_batch (rank-local part);
+ * dlogits = (softmax - onehot) * inv_batch; dW = dlogits^T X; db = sum dlogits; dX = dlogits W.
+ * Two launches (wave per sample, then the BxD contraction).  X [B][D], W [C][D], labels int64 [B];
+ * C <= 128.  ws: mla_head_ws_elems(B, C) floats. */
+size_t mla_head_ws_elems(int B, int C);
+int mla_head_ce_fwd_bwd(const float* X, const float* W, const float* b, const int64_t* labels,
+                        float* logits, float* loss, float* dW, float* db, float* dX, float* ws,
+                        int B, int D, int C, float inv_batch, void* stream);
+
+/* ---- GSPlugin.before_update (utils/utils.py:24-41) ------------------------------------------- */
+/* r[j] = scale * sum_i X[i][j]   (column mean with scale = 1/B; rank-local column sum otherwise) */
+int mla_colsum(const float* X, float* r, int B, int D, float scale, void* stream);
+/* k = Pl r^T; Pl <- Pl - (k k^T) ./ (alpha + k r) ; Pl <- Pl/||Pl||_F ; G <- G Pl^T.
+ * Pl [D][D] and G [C][D] are updated in place.  ws: mla_gs_ws_elems(D, C) floats. */
+size_t mla_gs_ws_elems(int D, int C);
+int mla_gs_project(float* Pl, const float* r, float* G, int D, int C, float alpha, float* ws, void* stream);
+
+/* ---- torch.optim.SGD(momentum, weight_decay) (main.py:749, 439, 451) ------------------------- */
+/* d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf.  g == NULL means zero gradient
+ * (torch-1.8.1 zero_grad semantics).  One flat launch over n contiguous elements. */
+int mla_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd,
+                 int first, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLA_HIP_H */

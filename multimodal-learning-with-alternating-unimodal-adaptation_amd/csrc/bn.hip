@@ -1,0 +1,222 @@
+// BatchNorm2d (training mode) over pixel-major [M][C] fp32 activations, gfx950.
+//
+// Replaces the ATen batch_norm forward/backward that nn.BatchNorm2d triggers in the reference
+// (models/backbone.py:29, 32, 86, 128; momentum 0.1, eps 1e-5, biased batch variance for the
+// normalisation, unbiased for running_var) together with the in-place ReLU and the residual add
+// of BasicBlock.forward (backbone.py:41, 49-50), which are fused into the apply pass.
+//
+// HBM-bound: every pass is float4-vectorised with channels on the fast axis, so a wave reads
+// whole 256-B..1-KiB pixel rows; per-channel reductions are thread-private over a row stripe,
+// then LDS across row lanes, then fp64 across tiles (mla_bn_finalize) -- no atomics, results are
+// bitwise reproducible.  Statistics normally arrive pre-reduced from the conv epilogue
+// (conv_igemm.hip), saving one full read of the activation.
+#include "common.h"
+
+// ---- tiling shared by the stats and backward-reduce kernels --------------------------------
+static int bn_tile_rows(int M) {
+  long t = ((long)M + 2047) / 2048;  // aim at ~2048 workgroups
+  t = ((t + 15) / 16) * 16;
+  if (t < 32) t = 32;
+  if (t > 1024) t = 1024;
+  return (int)t;
+}
+
+extern "C" size_t mla_bn_stats_partial_elems(int M, int C) {
+  return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C;
+}
+extern "C" size_t mla_bn_bwd_ws_elems(int M, int C) { return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C + 2 * C; }
+
+// Reduce two per-channel quantities over a tile of rows.  MODE 0: (x, x^2).  MODE 1: (g, g*xhat).
+// Block: 256 threads = (C/4 column groups) x (row lanes); C/4 <= 256 and divides 256.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                         const float* __restrict__ relu_out,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         float* __restrict__ partial, int M, int C, int tile_rows) {
+  __shared__ f32x4 red[2][256];
+  const int c4n = C >> 2;
+  const int cg = threadIdx.x % c4n, rl = threadIdx.x / c4n, nrl = 256 / c4n;
+  const int r0 = blockIdx.x * tile_rows, r1 = min(M, r0 + tile_rows);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+  if (MODE == 1) {
+    mu = reinterpret_cast<const f32x4*>(mean)[cg];
+    is = reinterpret_cast<const f32x4*>(invstd)[cg];
+  }
+  for (int r = r0 + rl; r < r1; r += nrl) {
+    const size_t idx = (size_t)r * c4n + cg;
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
+    if (MODE == 0) {
+      s0 += xv;
+      s1 += xv * xv;
+    } else {
+      f32x4 g = reinterpret_cast<const f32x4*>(dout)[idx];
+      if (relu_out) {
+        const f32x4 o = reinterpret_cast<const f32x4*>(relu_out)[idx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+      }
+      s0 += g;
+      s1 += g * ((xv - mu) * is);
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < nrl; ++k) {
+      s0 += red[0][k * c4n + cg];
+      s1 += red[1][k * c4n + cg];
+    }
+    reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * C)[cg] = s0;
+    reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * C)[cg] = s1;
+  }
+}
+
+// One wave per channel: fp64 sum over tiles of partial[t][0|1][c].
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles, int M, int C,
+                                                           float eps, float momentum, float* __restrict__ mean,
+                                                           float* __restrict__ invstd, float* running_mean,
+                                                           float* running_var) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int t = lane; t < tiles; t += 64) {
+    s += (double)partial[((size_t)t * 2 + 0) * C + c];
+    q += (double)partial[((size_t)t * 2 + 1) * C + c];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane == 0) {
+    const double m = s / M;
+    double var = q / M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unb = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  }
+}
+
+// dgamma/dbeta totals for the backward: sums partial[t][0|1][c] -> tot[0|1][c] (fp64 inside).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int tiles, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int t = lane; t < tiles; t += 64) {
+    s += (double)partial[((size_t)t * 2 + 0) * C + c];
+    q += (double)partial[((size_t)t * 2 + 1) * C + c];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane == 0) {
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* residual, float* out, size_t n4, int c4n, int relu) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c4n);
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
+    f32x4 v = (reinterpret_cast<const f32x4*>(x)[idx] - mu) * is * ga + be;
+    if (residual) v += reinterpret_cast<const f32x4*>(residual)[idx];
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    reinterpret_cast<f32x4*>(out)[idx] = v;
+  }
+}
+
+// dx may alias dout (in place): every element is read before it is written by the same thread.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, const float* __restrict__ relu_out,
+                                                            const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ dgamma,
+                                                            const float* __restrict__ dbeta, float* dx, float* g_out,
+                                                            size_t n4, int c4n, float invM) {
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % c4n);
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg];
+    const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[cg] * invM, db = reinterpret_cast<const f32x4*>(dbeta)[cg] * invM;
+    f32x4 g = reinterpret_cast<const f32x4*>(dout)[idx];
+    if (relu_out) {
+      const f32x4 o = reinterpret_cast<const f32x4*>(relu_out)[idx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+    }
+    const f32x4 xhat = (reinterpret_cast<const f32x4*>(x)[idx] - mu) * is;
+    if (g_out) reinterpret_cast<f32x4*>(g_out)[idx] = g;
+    reinterpret_cast<f32x4*>(dx)[idx] = ga * is * (g - db - xhat * dg);
+  }
+}
+
+static int bn_check(const char* who, int M, int C) {
+  MLA_REQUIRE(M > 0 && C > 0, "%s: non-positive dims", who);
+  MLA_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "%s: C=%d must be 4*2^k, <= 1024", who, C);
+  return MLA_OK;
+}
+
+static int ew_grid(size_t n4) {
+  size_t b = (n4 + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+extern "C" int mla_bn_stats_partial(const float* x, int M, int C, float* partial, int* tiles, void* stream) {
+  if (int rc = bn_check("mla_bn_stats_partial", M, C)) return rc;
+  MLA_REQUIRE(x && partial, "mla_bn_stats_partial: null pointer");
+  const int tr = bn_tile_rows(M), nt = cdiv(M, tr);
+  bn_reduce_kernel<0><<<nt, 256, 0, (hipStream_t)stream>>>(x, nullptr, nullptr, nullptr, nullptr, partial, M, C, tr);
+  MLA_CHECK_LAUNCH("bn_reduce_kernel<0>");
+  if (tiles) *tiles = nt;
+  return MLA_OK;
+}
+
+extern "C" int mla_bn_finalize(const float* partial, int tiles, int M, int C, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, void* stream) {
+  MLA_REQUIRE(partial && mean && invstd && tiles > 0 && M > 0 && C > 0, "mla_bn_finalize: bad argument");
+  MLA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mla_bn_finalize: running stats must come in pairs");
+  bn_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partial, tiles, M, C, eps, momentum, mean, invstd,
+                                                                 running_mean, running_var);
+  MLA_CHECK_LAUNCH("bn_finalize_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_bn_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, const float* residual, float* out, int M, int C, int relu, void* stream) {
+  if (int rc = bn_check("mla_bn_apply", M, C)) return rc;
+  MLA_REQUIRE(x && mean && invstd && gamma && beta && out, "mla_bn_apply: null pointer");
+  const size_t n4 = (size_t)M * C / 4;
+  bn_apply_kernel<<<ew_grid(n4), 256, 0, (hipStream_t)stream>>>(x, mean, invstd, gamma, beta, residual, out, n4, C / 4, relu);
+  MLA_CHECK_LAUNCH("bn_apply_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float* x, const float* mean,
+                          const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta, float* g_out,
+                          float* ws, int M, int C, void* stream) {
+  if (int rc = bn_check("mla_bn_bwd", M, C)) return rc;
+  MLA_REQUIRE(dout && x && mean && invstd && gamma && dx && dgamma && dbeta && ws, "mla_bn_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int tr = bn_tile_rows(M), nt = cdiv(M, tr);
+  bn_reduce_kernel<1><<<nt, 256, 0, st>>>(x, dout, relu_out, mean, invstd, ws, M, C, tr);
+  MLA_CHECK_LAUNCH("bn_reduce_kernel<1>");
+  bn_bwd_finalize_kernel<<<cdiv(C, 4), 256, 0, st>>>(ws, nt, C, dgamma, dbeta);
+  MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  const size_t n4 = (size_t)M * C / 4;
+  bn_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(dout, relu_out, x, mean, invstd, gamma, dgamma, dbeta, dx, g_out, n4,
+                                                   C / 4, 1.0f / (float)M);
+  MLA_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return MLA_OK;
+}

@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels of libmla_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mla_hip.h"
+
+#define MLA_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void mla_set_error(const char* fmt, ...);
+
+#define MLA_REQUIRE(cond, ...)              \
+  do {                                      \
+    if (!(cond)) {                          \
+      mla_set_error(__VA_ARGS__);           \
+      return MLA_ERR_INVALID_ARG;           \
+    }                                       \
+  } while (0)
+
+#define MLA_CHECK_LAUNCH(name)                                             \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      mla_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return MLA_ERR_LAUNCH;                                               \
+    }                                                                      \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a flat workgroup id: consecutive logical ids land on the same XCD
+// (blocks b and b+8 share an XCD/L2 under round-robin dispatch).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, l = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}

@@ -1,0 +1,213 @@
+// Latency-bound small kernels on the critical path between the two modalities:
+//   shared head + cross entropy   ConcatFusion.fc_out = nn.Linear(D,C) (models/fusion_modules.py:19) applied per
+//                                 modality (main.py:432, 444) + nn.CrossEntropyLoss (main.py:130) + autograd
+//   head-gradient projection      GSPlugin.before_update (utils/utils.py:24-41), literal
+//   SGD momentum + weight decay   torch.optim.SGD.step (main.py:749, 439, 451), one flat launch per group
+// Wave-per-row kernels with 64-lane shuffle reductions; no atomics (bitwise reproducible).
+#include "common.h"
+
+#define HEAD_MAXC 128
+
+// ---- head: one wave per sample -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const int64_t* __restrict__ labels,
+                                                        float* __restrict__ logits, float* __restrict__ rowloss,
+                                                        float* __restrict__ dlogits, float* __restrict__ dX, int B, int D,
+                                                        int C, float inv_batch) {
+  __shared__ float lg[4][HEAD_MAXC];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= B) return;  // wave-uniform; no block-level barrier below
+  const float* x = X + (size_t)row * D;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += x[d] * W[(size_t)c * D + d];
+    s = wave_sum(s);
+    if (lane == 0) lg[wave][c] = s + bias[c];
+  }
+  __builtin_amdgcn_wave_barrier();
+  float l0 = lane < C ? lg[wave][lane] : -INFINITY;
+  float l1 = lane + 64 < C ? lg[wave][lane + 64] : -INFINITY;
+  const float m = wave_max(fmaxf(l0, l1));
+  const float e0 = lane < C ? expf(l0 - m) : 0.f, e1 = lane + 64 < C ? expf(l1 - m) : 0.f;
+  const float s = wave_sum(e0 + e1);
+  const int lab = (int)labels[row];
+  const float lse = m + logf(s);
+  if (lane < C) logits[(size_t)row * C + lane] = l0;
+  if (lane + 64 < C) logits[(size_t)row * C + lane + 64] = l1;
+  if (lane == 0) rowloss[row] = (lse - lg[wave][lab]) * inv_batch;
+  __builtin_amdgcn_wave_barrier();
+  const float d0 = (e0 / s - (lane == lab ? 1.f : 0.f)) * inv_batch;
+  const float d1 = (e1 / s - (lane + 64 == lab ? 1.f : 0.f)) * inv_batch;
+  if (lane < C) {
+    lg[wave][lane] = d0;
+    dlogits[(size_t)row * C + lane] = d0;
+  }
+  if (lane + 64 < C) {
+    lg[wave][lane + 64] = d1;
+    dlogits[(size_t)row * C + lane + 64] = d1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < D; d += 64) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += lg[wave][c] * W[(size_t)c * D + d];
+    dX[(size_t)row * D + d] = a;
+  }
+}
+
+// grid (ceil(D/256), C): dW[c][d] = sum_rows dl[row][c] X[row][d]; block (0,c) also db[c]; block (0,0) the loss.
+__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ X, const float* __restrict__ dlogits,
+                                                         const float* __restrict__ rowloss, float* __restrict__ dW,
+                                                         float* __restrict__ db, float* __restrict__ loss, int B, int D, int C) {
+  const int c = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  if (d < D) {
+    float a = 0.f;
+    for (int r = 0; r < B; ++r) a += dlogits[(size_t)r * C + c] * X[(size_t)r * D + d];
+    dW[(size_t)c * D + d] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    float a = 0.f;
+    for (int r = threadIdx.x; r < B; r += 64) a += dlogits[(size_t)r * C + c];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) db[c] = a;
+    if (c == 0) {
+      float l = 0.f;
+      for (int r = threadIdx.x; r < B; r += 64) l += rowloss[r];
+      l = wave_sum(l);
+      if (threadIdx.x == 0) *loss = l;
+    }
+  }
+}
+
+extern "C" size_t mla_head_ws_elems(int B, int C) { return (size_t)B * C + B; }
+
+extern "C" int mla_head_ce_fwd_bwd(const float* X, const float* W, const float* b, const int64_t* labels, float* logits,
+                                   float* loss, float* dW, float* db, float* dX, float* ws, int B, int D, int C,
+                                   float inv_batch, void* stream) {
+  MLA_REQUIRE(X && W && b && labels && logits && loss && dW && db && dX && ws, "mla_head_ce_fwd_bwd: null pointer");
+  MLA_REQUIRE(B > 0 && D > 0 && C > 0 && C <= HEAD_MAXC, "mla_head_ce_fwd_bwd: need 0 < C <= %d (got %d)", HEAD_MAXC, C);
+  hipStream_t st = (hipStream_t)stream;
+  float* dlogits = ws;
+  float* rowloss = ws + (size_t)B * C;
+  head_fwd_kernel<<<cdiv(B, 4), 256, 0, st>>>(X, W, b, labels, logits, rowloss, dlogits, dX, B, D, C, inv_batch);
+  MLA_CHECK_LAUNCH("head_fwd_kernel");
+  head_grad_kernel<<<dim3(cdiv(D, 256), C), 256, 0, st>>>(X, dlogits, rowloss, dW, db, loss, B, D, C);
+  MLA_CHECK_LAUNCH("head_grad_kernel");
+  return MLA_OK;
+}
+
+// ---- column sum ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ r, int B, int D, float scale) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float a = 0.f;
+  for (int i = 0; i < B; ++i) a += X[(size_t)i * D + d];
+  r[d] = a * scale;
+}
+
+extern "C" int mla_colsum(const float* X, float* r, int B, int D, float scale, void* stream) {
+  MLA_REQUIRE(X && r && B > 0 && D > 0, "mla_colsum: bad argument");
+  colsum_kernel<<<cdiv(D, 256), 256, 0, (hipStream_t)stream>>>(X, r, B, D, scale);
+  MLA_CHECK_LAUNCH("colsum_kernel");
+  return MLA_OK;
+}
+
+// ---- GS projection: three row-parallel phases (wave per row of Pl) ---------------------------------
+// A: k = Pl r^T
+__global__ __launch_bounds__(256) void gs_k_kernel(const float* __restrict__ Pl, const float* __restrict__ r,
+                                                    float* __restrict__ k, int D) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= D) return;
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) s += Pl[(size_t)i * D + j] * r[j];
+  s = wave_sum(s);
+  if (lane == 0) k[i] = s;
+}
+// B: Pl[i][j] -= k_i k_j / (alpha + k_i r_j)   (element-wise DxD denominator, utils/utils.py:36); row sums of squares
+__global__ __launch_bounds__(256) void gs_update_kernel(float* __restrict__ Pl, const float* __restrict__ r,
+                                                         const float* __restrict__ k, float* __restrict__ rowsq, int D,
+                                                         float alpha) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= D) return;
+  const float ki = k[i];
+  float q = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float v = Pl[(size_t)i * D + j] - (ki * k[j]) / (alpha + ki * r[j]);
+    Pl[(size_t)i * D + j] = v;
+    q += v * v;
+  }
+  q = wave_sum(q);
+  if (lane == 0) rowsq[i] = q;
+}
+// C: Pl /= ||Pl||_F ; Gout[c][i] = sum_j G[c][j] Pl[i][j]
+__global__ __launch_bounds__(256) void gs_finish_kernel(float* __restrict__ Pl, const float* __restrict__ rowsq,
+                                                         const float* __restrict__ G, float* __restrict__ Gout, int D, int C) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= D) return;
+  double t = 0.0;
+  for (int j = lane; j < D; j += 64) t += (double)rowsq[j];
+  t = wave_sum_d(t);
+  const float nrm = (float)sqrt(t);
+  for (int j = lane; j < D; j += 64) Pl[(size_t)i * D + j] = Pl[(size_t)i * D + j] / nrm;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int j = lane; j < D; j += 64) s += G[(size_t)c * D + j] * Pl[(size_t)i * D + j];
+    s = wave_sum(s);
+    if (lane == 0) Gout[(size_t)c * D + i] = s;
+  }
+}
+
+extern "C" size_t mla_gs_ws_elems(int D, int C) { return (size_t)2 * D + (size_t)C * D; }
+
+extern "C" int mla_gs_project(float* Pl, const float* r, float* G, int D, int C, float alpha, float* ws, void* stream) {
+  MLA_REQUIRE(Pl && r && G && ws && D > 0 && C > 0, "mla_gs_project: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  float *k = ws, *rowsq = ws + D, *Gtmp = ws + 2 * (size_t)D;
+  gs_k_kernel<<<cdiv(D, 4), 256, 0, st>>>(Pl, r, k, D);
+  MLA_CHECK_LAUNCH("gs_k_kernel");
+  gs_update_kernel<<<cdiv(D, 4), 256, 0, st>>>(Pl, r, k, rowsq, D, alpha);
+  MLA_CHECK_LAUNCH("gs_update_kernel");
+  gs_finish_kernel<<<cdiv(D, 4), 256, 0, st>>>(Pl, rowsq, G, Gtmp, D, C);
+  MLA_CHECK_LAUNCH("gs_finish_kernel");
+  if (hipMemcpyAsync(G, Gtmp, (size_t)C * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    mla_set_error("mla_gs_project: hipMemcpyAsync failed");
+    return MLA_ERR_LAUNCH;
+  }
+  return MLA_OK;
+}
+
+// ---- SGD -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                   size_t n, float lr, float momentum, float wd, int first) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 d = pv * wd;
+    if (g) d += reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 b = first ? d : reinterpret_cast<f32x4*>(buf)[i] * momentum + d;
+    reinterpret_cast<f32x4*>(buf)[i] = b;
+    reinterpret_cast<f32x4*>(p)[i] = pv - b * lr;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = (n4 << 2) + threadIdx.x;
+    const float pv = p[i];
+    const float d = (g ? g[i] : 0.f) + wd * pv;
+    const float b = first ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    p[i] = pv - lr * b;
+  }
+}
+
+extern "C" int mla_sgd_step(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first,
+                            void* stream) {
+  MLA_REQUIRE(p && buf, "mla_sgd_step: null pointer");
+  if (n == 0) return MLA_OK;
+  MLA_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)buf % 16 == 0) && (!g || (uintptr_t)g % 16 == 0),
+              "mla_sgd_step: buffers must be 16-byte aligned");
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  sgd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, first);
+  MLA_CHECK_LAUNCH("sgd_kernel");
+  return MLA_OK;
+}

@@ -1,0 +1,12 @@
+"""mla_hip: MI355X-native MLA alternating-unimodal training step (HIP kernels behind a C ABI).
+
+Importing the package does not touch the GPU; the first op loads libmla_hip.so and raises
+MLAHipError if it is missing (there is no CPU or eager fallback).
+"""
+from ._lib import MLAHipError, LIB_PATH  # noqa: F401
+from .dist import Comm  # noqa: F401
+from .encoder import ResNet18Encoder  # noqa: F401
+from .model import AVClassifier, ConcatFusion, SharedHead  # noqa: F401
+from .optim import FusedSGD  # noqa: F401
+from .plugin import GSPlugin  # noqa: F401
+from .trainer import MLATrainer  # noqa: F401

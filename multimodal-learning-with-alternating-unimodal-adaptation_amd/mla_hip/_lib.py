@@ -1,0 +1,80 @@
+"""ctypes binding of libmla_hip.so (C ABI declared in include/mla_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or a call fails, an
+exception is raised (`MLAHipError`).  PyTorch is only used for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmla_hip.so")
+
+
+class MLAHipError(RuntimeError):
+    pass
+
+
+_P, _I, _F, _Z = c_void_p, c_int, c_float, c_size_t
+
+# name -> (restype, argtypes); mirrors include/mla_hip.h one-to-one (tests/test_abi.py checks this)
+PROTOTYPES = {
+    "mla_abi_version": (_I, []),
+    "mla_last_error": (c_char_p, []),
+    "mla_video_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mla_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mla_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mla_conv2d_fwd_partial_elems": (_Z, [_I] * 9),
+    "mla_conv2d_fwd": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
+    "mla_conv2d_dgrad": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P]),
+    "mla_conv2d_wgrad_ws_bytes": (_Z, [_I] * 9),
+    "mla_conv2d_wgrad": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
+    "mla_bn_stats_partial_elems": (_Z, [_I, _I]),
+    "mla_bn_stats_partial": (_I, [_P, _I, _I, _P, _P, _P]),
+    "mla_bn_finalize": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P]),
+    "mla_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mla_bn_bwd_ws_elems": (_Z, [_I, _I]),
+    "mla_bn_bwd": (_I, [_P] * 11 + [_I, _I, _P]),
+    "mla_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "mla_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mla_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mla_avgpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mla_head_ws_elems": (_Z, [_I, _I]),
+    "mla_head_ce_fwd_bwd": (_I, [_P] * 10 + [_I, _I, _I, _F, _P]),
+    "mla_colsum": (_I, [_P, _P, _I, _I, _F, _P]),
+    "mla_gs_ws_elems": (_Z, [_I, _I]),
+    "mla_gs_project": (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),
+    "mla_sgd_step": (_I, [_P, _P, _P, _Z, _F, _F, _F, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libmla_hip.so (once).  Raises MLAHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MLAHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C multimodal-learning-with-alternating-unimodal-adaptation_amd/csrc`). "
+            "mla_hip has no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise MLAHipError(f"libmla_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, who: str) -> None:
+    if rc != 0:
+        msg = load().mla_last_error()
+        raise MLAHipError(f"{who} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,341 @@
+"""ResNet-18 modality encoder on the HIP kernels (reference: models/backbone.py:15-52, 55-160, 211-213).
+
+MI355X-first host design, not a module-by-module port:
+  * all parameters of an encoder live in ONE flat fp32 buffer (conv weights HWIO, then BN
+    gamma/beta), gradients and SGD momentum in two more of the same shape, so the optimiser is a
+    single launch and data-parallel gradient exchange is a single RCCL all-reduce over 44.7 MB;
+  * activations are pixel-major NHWC so the implicit-GEMM gathers whole channel rows and the
+    BatchNorm passes stream float4 with channels on the fast axis;
+  * forward and backward are explicit launch plans over a per-shape workspace that is allocated
+    once (288 GB of HBM: nothing is recomputed, nothing is allocated in steady state);
+  * BatchNorm statistics come out of the conv epilogue; ReLU masks and residual adds ride in the
+    dgrad / BN-apply epilogues, so no standalone element-wise kernels exist.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import MLAHipError
+
+
+def conv_specs(modality: str) -> List[Tuple[str, int, int, int, int, int]]:
+    """(state_dict prefix, cin, cout, k, stride, pad) in reference module order (backbone.py:78-95, 118-140)."""
+    if modality not in ("audio", "visual"):
+        # same error behaviour as backbone.py:84-85
+        raise NotImplementedError("Incorrect modality, should be audio or visual but got {}".format(modality))
+    specs = [("conv1", 1 if modality == "audio" else 3, 64, 7, 2, 3)]
+    inpl = 64
+    for li, planes in enumerate([64, 128, 256, 512], start=1):
+        for bi in range(2):
+            stride = 2 if (li > 1 and bi == 0) else 1
+            specs.append((f"layer{li}.{bi}.conv1", inpl, planes, 3, stride, 1))
+            specs.append((f"layer{li}.{bi}.conv2", planes, planes, 3, 1, 1))
+            if bi == 0 and (stride != 1 or inpl != planes):
+                specs.append((f"layer{li}.{bi}.downsample.0", inpl, planes, 1, stride, 0))
+            inpl = planes
+    return specs
+
+
+def bn_name_for_conv(conv_name: str) -> str:
+    if conv_name == "conv1":
+        return "bn1"
+    if conv_name.endswith("downsample.0"):
+        return conv_name[:-1] + "1"
+    return conv_name.replace("conv", "bn")
+
+
+class ResNet18Encoder:
+    """ResNet-18 trunk without avgpool/fc (backbone.py:96-99), training-mode BatchNorm."""
+
+    def __init__(self, modality: str, device="cuda", seed: Optional[int] = None):
+        self.modality = modality
+        self.device = torch.device(device)
+        self.specs = conv_specs(modality)
+        # ---- flat layout: name -> (offset, shape); conv weights HWIO
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for name, cin, cout, k, _s, _p in self.specs:
+            self.layout[name + ".weight"] = (off, (k, k, cin, cout))
+            off += k * k * cin * cout
+        for name, _cin, cout, _k, _s, _p in self.specs:
+            bn = bn_name_for_conv(name)
+            self.layout[bn + ".weight"] = (off, (cout,))
+            off += cout
+            self.layout[bn + ".bias"] = (off, (cout,))
+            off += cout
+        self.numel = off
+        self.flat = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.p = {k: self.flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
+        self.g = {k: self.grad[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
+        # ---- BN buffers (one flat buffer: running_mean | running_var per BN)
+        self.bn_names = [bn_name_for_conv(n) for n, *_ in self.specs]
+        self.bn_ch = {bn_name_for_conv(n): cout for n, _ci, cout, *_ in self.specs}
+        tot = sum(self.bn_ch.values())
+        self.running = torch.zeros(2 * tot, device=self.device, dtype=torch.float32)
+        self.rm, self.rv = {}, {}
+        o = 0
+        for bn in self.bn_names:
+            c = self.bn_ch[bn]
+            self.rm[bn] = self.running[o:o + c]
+            self.rv[bn] = self.running[tot + o:tot + o + c]
+            o += c
+        self.running[tot:].fill_(1.0)
+        self.num_batches_tracked = {bn: 0 for bn in self.bn_names}
+        self.grad_ready = False
+        self._plan_key = None
+        self._ws: dict = {}
+        self.reset_parameters(seed)
+
+    # ------------------------------------------------------------------------------------------
+    # parameters / state_dict (reference keys and OIHW layout at the boundary)
+    # ------------------------------------------------------------------------------------------
+    def reset_parameters(self, seed: Optional[int] = None) -> None:
+        """utils/utils.py:106-114 weight_init (overrides backbone.py:101-106): kaiming-normal fan_out, BN 1/0."""
+        gen = torch.Generator(device="cpu")
+        if seed is not None:
+            gen.manual_seed(seed)
+        else:
+            gen.seed()
+        for name, cin, cout, k, _s, _p in self.specs:
+            std = math.sqrt(2.0 / (cout * k * k))
+            w = torch.randn((k, k, cin, cout), generator=gen) * std
+            self.p[name + ".weight"].copy_(w)
+            bn = bn_name_for_conv(name)
+            self.p[bn + ".weight"].fill_(1.0)
+            self.p[bn + ".bias"].zero_()
+
+    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
+        sd = {}
+        for name, *_ in self.specs:
+            sd[prefix + name + ".weight"] = self.p[name + ".weight"].permute(3, 2, 0, 1).contiguous()
+            bn = bn_name_for_conv(name)
+            sd[prefix + bn + ".weight"] = self.p[bn + ".weight"].clone()
+            sd[prefix + bn + ".bias"] = self.p[bn + ".bias"].clone()
+            sd[prefix + bn + ".running_mean"] = self.rm[bn].clone()
+            sd[prefix + bn + ".running_var"] = self.rv[bn].clone()
+            sd[prefix + bn + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked[bn], dtype=torch.int64)
+        # reference module order: conv, bn pairs
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
+        for name, *_ in self.specs:
+            keys = [name + ".weight"]
+            bn = bn_name_for_conv(name)
+            keys += [bn + ".weight", bn + ".bias", bn + ".running_mean", bn + ".running_var"]
+            for k in keys:
+                if prefix + k not in sd:
+                    if strict:
+                        raise KeyError(f"missing key {prefix + k}")
+                    continue
+                t = sd[prefix + k].to(device=self.device, dtype=torch.float32)
+                if k == name + ".weight":
+                    self.p[k].copy_(t.permute(2, 3, 1, 0))       # OIHW -> HWIO
+                elif k.endswith("running_mean"):
+                    self.rm[bn].copy_(t)
+                elif k.endswith("running_var"):
+                    self.rv[bn].copy_(t)
+                else:
+                    self.p[k].copy_(t)
+            nbt = sd.get(prefix + bn + ".num_batches_tracked")
+            if nbt is not None:
+                self.num_batches_tracked[bn] = int(nbt)
+
+    def grads_as_reference(self) -> Dict[str, torch.Tensor]:
+        """Gradients keyed/laid out like the reference's named_parameters() (OIHW)."""
+        out = {}
+        for k in self.layout:
+            t = self.g[k]
+            out[k] = t.permute(3, 2, 0, 1).contiguous() if t.dim() == 4 else t.clone()
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # workspace plan
+    # ------------------------------------------------------------------------------------------
+    def _plan(self, N: int, H: int, W: int) -> dict:
+        key = (N, H, W)
+        if self._plan_key == key:
+            return self._ws
+        dev = self.device
+        ws: dict = {"shapes": {}}
+        f32 = dict(device=dev, dtype=torch.float32)
+        cin0 = self.specs[0][1]
+        # forward activation shapes
+        h1, w1 = ops.conv_out(H, 7, 2, 3), ops.conv_out(W, 7, 2, 3)
+        hp, wp = ops.conv_out(h1, 3, 2, 1), ops.conv_out(w1, 3, 2, 1)
+        ws["x0_shape"] = (N, H, W, cin0)
+        ws["y_stem"] = torch.empty((N, h1, w1, 64), **f32)
+        ws["a_stem"] = torch.empty((N, h1, w1, 64), **f32)
+        ws["p0"] = torch.empty((N, hp, wp, 64), **f32)
+        ws["pool_idx"] = torch.empty((N, hp, wp, 64), device=dev, dtype=torch.uint8)
+        max_act = N * h1 * w1 * 64
+        max_partial = ops.conv2d_fwd_partial_elems(N, H, W, cin0, 64, 7, 7, 2, 3)
+        max_wgrad = ops.conv2d_wgrad_ws_bytes(N, H, W, cin0, 64, 7, 7, 2, 3)
+        max_bnws = ops.bn_bwd_ws_elems(N * h1 * w1, 64)
+        max_w = 0
+        ch, cw, inpl = hp, wp, 64
+        blocks = []
+        for li, planes in enumerate([64, 128, 256, 512], start=1):
+            for bi in range(2):
+                pre = f"layer{li}.{bi}"
+                stride = 2 if (li > 1 and bi == 0) else 1
+                oh, ow = ops.conv_out(ch, 3, stride, 1), ops.conv_out(cw, 3, stride, 1)
+                has_ds = bi == 0 and (stride != 1 or inpl != planes)
+                blk = {"pre": pre, "stride": stride, "cin": inpl, "cout": planes, "in_hw": (ch, cw), "out_hw": (oh, ow),
+                       "ds": has_ds}
+                for nm in ("y1", "a1", "y2", "out"):
+                    blk[nm] = torch.empty((N, oh, ow, planes), **f32)
+                if has_ds:
+                    blk["yd"] = torch.empty((N, oh, ow, planes), **f32)
+                blocks.append(blk)
+                max_act = max(max_act, N * oh * ow * planes, N * ch * cw * inpl)
+                for (ci, co, k, s, p, hh, ww) in ((inpl, planes, 3, stride, 1, ch, cw), (planes, planes, 3, 1, 1, oh, ow)) + \
+                        (((inpl, planes, 1, stride, 0, ch, cw),) if has_ds else ()):
+                    max_partial = max(max_partial, ops.conv2d_fwd_partial_elems(N, hh, ww, ci, co, k, k, s, p))
+                    max_wgrad = max(max_wgrad, ops.conv2d_wgrad_ws_bytes(N, hh, ww, ci, co, k, k, s, p))
+                    max_w = max(max_w, ci * co * k * k)
+                max_bnws = max(max_bnws, ops.bn_bwd_ws_elems(N * oh * ow, planes))
+                ch, cw, inpl = oh, ow, planes
+        ws["blocks"] = blocks
+        ws["feat_hw"] = (ch, cw)
+        ws["idn"] = torch.empty(max_act, **f32)                       # bn(downsample) temp
+        ws["partial"] = torch.empty(max(max_partial, 1), **f32)
+        ws["stats"] = {bn: (torch.empty(self.bn_ch[bn], **f32), torch.empty(self.bn_ch[bn], **f32)) for bn in self.bn_names}
+        # backward scratch (allocated lazily on first backward)
+        ws["bwd_sizes"] = (max_act, max_wgrad, max_w, max_bnws)
+        self._ws, self._plan_key = ws, key
+        return ws
+
+    def _bwd_ws(self, ws: dict) -> None:
+        if "G" in ws:
+            return
+        max_act, max_wgrad, max_w, max_bnws = ws["bwd_sizes"]
+        f32 = dict(device=self.device, dtype=torch.float32)
+        ws["G"] = [torch.empty(max_act, **f32) for _ in range(4)]
+        ws["wgrad_ws"] = torch.empty((max_wgrad + 3) // 4, **f32)
+        ws["wt_ws"] = torch.empty(max_w, **f32)
+        ws["bn_ws"] = torch.empty(max_bnws, **f32)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _conv_bn(self, ws, st, x, conv_name, stride, pad, y, out, relu, residual=None):
+        """y = conv(x); BN statistics fused in the conv epilogue; out = [relu](bn(y) [+ residual])."""
+        w = self.p[conv_name + ".weight"]
+        bn = bn_name_for_conv(conv_name)
+        _, tiles = ops.conv2d_fwd(x, w, stride, pad, y=y, bn_partial=ws["partial"], stream=st)
+        C = w.shape[3]
+        M = y.numel() // C
+        mean, invstd = ws["stats"][bn]
+        ops.bn_finalize(ws["partial"], tiles, M, C, mean, invstd, self.rm[bn], self.rv[bn], stream=st)
+        self.num_batches_tracked[bn] += 1
+        ops.bn_apply(y, mean, invstd, self.p[bn + ".weight"], self.p[bn + ".bias"], out, M, C, relu, residual=residual,
+                     stream=st)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (B,1,H,W) audio or (B,3,T,H,W) visual, fp32, reference layout.  Returns the NHWC feature
+        map (N,h,w,512) of layer4 (backbone.py:142-160); activations are kept for backward()."""
+        st = ops.cur_stream()
+        if self.modality == "visual":
+            if x.dim() != 5:
+                raise MLAHipError("visual encoder expects (B,C,T,H,W)")
+            B, C, T, H, W = x.shape
+            N = B * T
+        else:
+            if x.dim() != 4 or x.shape[1] != 1:
+                raise MLAHipError("audio encoder expects (B,1,H,W)")
+            N, C, H, W = x.shape
+        if C != self.specs[0][1]:
+            raise MLAHipError(f"{self.modality} encoder expects {self.specs[0][1]} input channels, got {C}")
+        ws = self._plan(N, H, W)
+        x = x.contiguous()
+        if self.modality == "visual":
+            if "x0" not in ws:
+                ws["x0"] = torch.empty((N, H, W, C), device=self.device, dtype=torch.float32)
+            ops.video_to_nhwc(x, ws["x0"], stream=st)                      # backbone.py:144-147
+        else:
+            ws["x0"] = x.view(N, H, W, 1)                                  # C == 1: NCHW == NHWC
+        self._conv_bn(ws, st, ws["x0"], "conv1", 2, 3, ws["y_stem"], ws["a_stem"], relu=True)   # :149-151
+        ops.maxpool_fwd(ws["a_stem"], ws["p0"], ws["pool_idx"], stream=st)                      # :152
+        cur = ws["p0"]
+        for blk in ws["blocks"]:                                                                 # :154-157
+            pre = blk["pre"]
+            self._conv_bn(ws, st, cur, pre + ".conv1", blk["stride"], 1, blk["y1"], blk["a1"], relu=True)
+            if blk["ds"]:
+                idn = ws["idn"][:blk["yd"].numel()].view(blk["yd"].shape)
+                self._conv_bn(ws, st, cur, pre + ".downsample.0", blk["stride"], 0, blk["yd"], idn, relu=False)
+            else:
+                idn = cur
+            # out = relu(bn2(conv2(a1)) + identity)   (backbone.py:43-50)
+            self._conv_bn(ws, st, blk["a1"], pre + ".conv2", 1, 1, blk["y2"], blk["out"], relu=True, residual=idn)
+            blk["xin"] = cur
+            cur = blk["out"]
+        self.grad_ready = False
+        return cur
+
+    # ------------------------------------------------------------------------------------------
+    # backward (explicit; fills self.grad completely)
+    # ------------------------------------------------------------------------------------------
+    def _bn_bwd(self, ws, st, bn, dout, x, dx):
+        C = self.bn_ch[bn]
+        M = x.numel() // C
+        mean, invstd = ws["stats"][bn]
+        ops.bn_bwd(dout, x, mean, invstd, self.p[bn + ".weight"], dx, self.g[bn + ".weight"], self.g[bn + ".bias"],
+                   ws["bn_ws"], M, C, stream=st)
+
+    def backward_from_pooled(self, dfeat: torch.Tensor, P: int) -> None:
+        """dfeat: (NB, 512) gradient of the global-average-pooled feature (NB groups of P pixels)."""
+        ws = self._ws
+        st = ops.cur_stream()
+        self._bwd_ws(ws)
+        G = ws["G"]
+        last = ws["blocks"][-1]
+        out = last["out"]
+        NB = dfeat.shape[0]
+        d = G[0][:out.numel()].view(out.shape)
+        ops.avgpool_bwd(dfeat.contiguous(), d, NB, P, out.shape[3], relu_src=out, stream=st)
+        self._backward_trunk(ws, st)
+
+    def _backward_trunk(self, ws, st) -> None:
+        """Expects G[0] = gradient w.r.t. the last block's output, already masked by (out > 0)."""
+        G = ws["G"]
+        for bi_, blk in reversed(list(enumerate(ws["blocks"]))):
+            pre = blk["pre"]
+            oshape = blk["out"].shape
+            n_out = blk["out"].numel()
+            xin = blk["xin"]
+            d = G[0][:n_out].view(oshape)
+            dy2 = G[1][:n_out].view(oshape)
+            self._bn_bwd(ws, st, pre + ".bn2", d, blk["y2"], dy2)
+            w2 = self.p[pre + ".conv2.weight"]
+            ops.conv2d_wgrad(blk["a1"], dy2, self.g[pre + ".conv2.weight"], 1, 1, ws["wgrad_ws"], stream=st)
+            da1 = G[2][:n_out].view(oshape)
+            ops.conv2d_dgrad(dy2, w2, oshape, 1, 1, ws["wt_ws"], dx=da1, relu_src=blk["a1"], stream=st)
+            self._bn_bwd(ws, st, pre + ".bn1", da1, blk["y1"], da1)          # in place: dy1 overwrites da1
+            dy1 = da1
+            w1 = self.p[pre + ".conv1.weight"]
+            ops.conv2d_wgrad(xin, dy1, self.g[pre + ".conv1.weight"], blk["stride"], 1, ws["wgrad_ws"], stream=st)
+            dx = G[3][:xin.numel()].view(xin.shape)
+            mask = xin if bi_ > 0 else None          # block input is a ReLU output except after the max-pool
+            if blk["ds"]:
+                dyd = G[1][:n_out].view(oshape)
+                self._bn_bwd(ws, st, pre + ".downsample.1", d, blk["yd"], dyd)
+                wd = self.p[pre + ".downsample.0.weight"]
+                ops.conv2d_wgrad(xin, dyd, self.g[pre + ".downsample.0.weight"], blk["stride"], 0, ws["wgrad_ws"], stream=st)
+                ops.conv2d_dgrad(dy1, w1, xin.shape, blk["stride"], 1, ws["wt_ws"], dx=dx, stream=st)
+                ops.conv2d_dgrad(dyd, wd, xin.shape, blk["stride"], 0, ws["wt_ws"], dx=dx, residual=dx, relu_src=mask, stream=st)
+            else:
+                ops.conv2d_dgrad(dy1, w1, xin.shape, blk["stride"], 1, ws["wt_ws"], dx=dx, residual=d, relu_src=mask, stream=st)
+            G[0], G[3] = G[3], G[0]
+        # stem: maxpool -> relu -> bn1 -> conv1
+        a_stem = ws["a_stem"]
+        dpool = G[0][:ws["p0"].numel()].view(ws["p0"].shape)
+        dstem = G[1][:a_stem.numel()].view(a_stem.shape)
+        ops.maxpool_bwd(dpool, ws["pool_idx"], dstem, a_stem.shape, relu_src=a_stem, stream=st)
+        self._bn_bwd(ws, st, "bn1", dstem, ws["y_stem"], dstem)
+        ops.conv2d_wgrad(ws["x0"], dstem, self.g["conv1.weight"], 2, 3, ws["wgrad_ws"], stream=st)
+        self.grad_ready = True

@@ -1,0 +1,196 @@
+"""Thin tensor-level wrappers over the C ABI (include/mla_hip.h).
+
+Every function takes CUDA(HIP) fp32 contiguous tensors, enqueues on `stream` (a raw
+hipStream_t handle; default = torch's current stream) and returns immediately.
+Activations are NHWC, conv weights HWIO.  No fallbacks: errors raise MLAHipError.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import MLAHipError, check
+
+BN_EPS = 1e-5        # nn.BatchNorm2d default (models/backbone.py:22)
+BN_MOMENTUM = 0.1
+
+
+def cur_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise MLAHipError(f"expected a contiguous {dtype} device tensor, got {t.dtype} {t.device} "
+                          f"contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def conv_out(n: int, k: int, s: int, p: int) -> int:
+    return (n + 2 * p - k) // s + 1
+
+
+# ---- layout -------------------------------------------------------------------------------------
+def video_to_nhwc(src: torch.Tensor, dst: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    B, C, T, H, W = src.shape
+    if dst is None:
+        dst = torch.empty((B * T, H, W, C), device=src.device, dtype=torch.float32)
+    check(_lib.load().mla_video_to_nhwc(_p(src), _p(dst), B, C, T, H, W, stream or cur_stream()), "mla_video_to_nhwc")
+    return dst
+
+
+def nchw_to_nhwc(src: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+    N, C, H, W = src.shape
+    dst = torch.empty((N, H, W, C), device=src.device, dtype=torch.float32)
+    check(_lib.load().mla_nchw_to_nhwc(_p(src), _p(dst), N, C, H, W, stream or cur_stream()), "mla_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src: torch.Tensor, stream: Optional[int] = None) -> torch.Tensor:
+    N, H, W, C = src.shape
+    dst = torch.empty((N, C, H, W), device=src.device, dtype=torch.float32)
+    check(_lib.load().mla_nhwc_to_nchw(_p(src), _p(dst), N, C, H, W, stream or cur_stream()), "mla_nhwc_to_nchw")
+    return dst
+
+
+# ---- convolution --------------------------------------------------------------------------------
+def conv2d_fwd_partial_elems(N, H, W, Cin, Cout, KH, KW, stride, pad) -> int:
+    return int(_lib.load().mla_conv2d_fwd_partial_elems(N, H, W, Cin, Cout, KH, KW, stride, pad))
+
+
+def conv2d_fwd(x: torch.Tensor, w_hwio: torch.Tensor, stride: int, pad: int, y: Optional[torch.Tensor] = None,
+               bn_partial: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+    """Returns (y, tiles).  If `bn_partial` is given it receives [tiles][2][Cout] column sums / sums of squares."""
+    N, H, W, Cin = x.shape
+    KH, KW, Cin2, Cout = w_hwio.shape
+    if Cin2 != Cin:
+        raise MLAHipError(f"conv2d_fwd: x has {Cin} channels, weight expects {Cin2}")
+    if y is None:
+        y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout), device=x.device,
+                        dtype=torch.float32)
+    tiles = ctypes.c_int(0)
+    check(_lib.load().mla_conv2d_fwd(_p(x), _p(w_hwio), _p(y), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                     _p(bn_partial), ctypes.addressof(tiles), stream or cur_stream()), "mla_conv2d_fwd")
+    return y, tiles.value
+
+
+def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_shape, stride: int, pad: int, wt_ws: torch.Tensor,
+                 dx: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                 relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    N, H, W, Cin = x_shape
+    KH, KW, _, Cout = w_hwio.shape
+    if dx is None:
+        dx = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
+    if wt_ws.numel() < w_hwio.numel():
+        raise MLAHipError("conv2d_dgrad: wt_ws too small")
+    check(_lib.load().mla_conv2d_dgrad(_p(dy), _p(w_hwio), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                       _p(residual), _p(relu_src), _p(wt_ws), stream or cur_stream()), "mla_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad) -> int:
+    return int(_lib.load().mla_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad))
+
+
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_hwio: torch.Tensor, stride: int, pad: int, ws: torch.Tensor,
+                 stream: Optional[int] = None) -> torch.Tensor:
+    N, H, W, Cin = x.shape
+    KH, KW, _, Cout = dw_hwio.shape
+    check(_lib.load().mla_conv2d_wgrad(_p(x), _p(dy), _p(dw_hwio), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                       _p(ws), ws.numel() * ws.element_size(), stream or cur_stream()), "mla_conv2d_wgrad")
+    return dw_hwio
+
+
+# ---- batch norm ---------------------------------------------------------------------------------
+def bn_stats_partial_elems(M: int, C: int) -> int:
+    return int(_lib.load().mla_bn_stats_partial_elems(M, C))
+
+
+def bn_stats_partial(x2d: torch.Tensor, M: int, C: int, partial: torch.Tensor, stream: Optional[int] = None) -> int:
+    tiles = ctypes.c_int(0)
+    check(_lib.load().mla_bn_stats_partial(_p(x2d), M, C, _p(partial), ctypes.addressof(tiles), stream or cur_stream()),
+          "mla_bn_stats_partial")
+    return tiles.value
+
+
+def bn_finalize(partial: torch.Tensor, tiles: int, M: int, C: int, mean: torch.Tensor, invstd: torch.Tensor,
+                running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
+                eps: float = BN_EPS, momentum: float = BN_MOMENTUM, stream: Optional[int] = None) -> None:
+    check(_lib.load().mla_bn_finalize(_p(partial), tiles, M, C, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
+                                      _p(running_var), stream or cur_stream()), "mla_bn_finalize")
+
+
+def bn_apply(x: torch.Tensor, mean, invstd, gamma, beta, out: torch.Tensor, M: int, C: int, relu: bool,
+             residual: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    check(_lib.load().mla_bn_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), _p(out), M, C,
+                                   int(relu), stream or cur_stream()), "mla_bn_apply")
+    return out
+
+
+def bn_bwd_ws_elems(M: int, C: int) -> int:
+    return int(_lib.load().mla_bn_bwd_ws_elems(M, C))
+
+
+def bn_bwd(dout, x, mean, invstd, gamma, dx, dgamma, dbeta, ws, M: int, C: int, relu_out=None, g_out=None,
+           stream: Optional[int] = None) -> None:
+    check(_lib.load().mla_bn_bwd(_p(dout), _p(relu_out), _p(x), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgamma),
+                                 _p(dbeta), _p(g_out), _p(ws), M, C, stream or cur_stream()), "mla_bn_bwd")
+
+
+# ---- pooling ------------------------------------------------------------------------------------
+def maxpool_fwd(x: torch.Tensor, y: torch.Tensor, idx: torch.Tensor, stream: Optional[int] = None) -> None:
+    N, H, W, C = x.shape
+    check(_lib.load().mla_maxpool3x3s2_fwd(_p(x), _p(y), _p(idx, torch.uint8), N, H, W, C, stream or cur_stream()),
+          "mla_maxpool3x3s2_fwd")
+
+
+def maxpool_bwd(dy, idx, dx, x_shape, relu_src=None, stream: Optional[int] = None) -> None:
+    N, H, W, C = x_shape
+    check(_lib.load().mla_maxpool3x3s2_bwd(_p(dy), _p(idx, torch.uint8), _p(relu_src), _p(dx), N, H, W, C,
+                                           stream or cur_stream()), "mla_maxpool3x3s2_bwd")
+
+
+def avgpool_fwd(x, y, NB: int, P: int, C: int, stream: Optional[int] = None) -> None:
+    check(_lib.load().mla_avgpool_fwd(_p(x), _p(y), NB, P, C, stream or cur_stream()), "mla_avgpool_fwd")
+
+
+def avgpool_bwd(dy, dx, NB: int, P: int, C: int, relu_src=None, stream: Optional[int] = None) -> None:
+    check(_lib.load().mla_avgpool_bwd(_p(dy), _p(relu_src), _p(dx), NB, P, C, stream or cur_stream()), "mla_avgpool_bwd")
+
+
+# ---- head / projection / optimiser ----------------------------------------------------------------
+def head_ws_elems(B: int, C: int) -> int:
+    return int(_lib.load().mla_head_ws_elems(B, C))
+
+
+def head_ce_fwd_bwd(X, W, b, labels, logits, loss, dW, db, dX, ws, inv_batch: float, stream: Optional[int] = None) -> None:
+    B, D = X.shape
+    C = W.shape[0]
+    check(_lib.load().mla_head_ce_fwd_bwd(_p(X), _p(W), _p(b), _p(labels, torch.int64), _p(logits), _p(loss), _p(dW),
+                                          _p(db), _p(dX), _p(ws), B, D, C, inv_batch, stream or cur_stream()),
+          "mla_head_ce_fwd_bwd")
+
+
+def colsum(X, r, scale: float, stream: Optional[int] = None) -> None:
+    B, D = X.shape
+    check(_lib.load().mla_colsum(_p(X), _p(r), B, D, scale, stream or cur_stream()), "mla_colsum")
+
+
+def gs_ws_elems(D: int, C: int) -> int:
+    return int(_lib.load().mla_gs_ws_elems(D, C))
+
+
+def gs_project(Pl, r, G, alpha: float, ws, stream: Optional[int] = None) -> None:
+    D = Pl.shape[0]
+    C = G.shape[0]
+    check(_lib.load().mla_gs_project(_p(Pl), _p(r), _p(G), D, C, alpha, _p(ws), stream or cur_stream()), "mla_gs_project")
+
+
+def sgd_step(p, g, buf, lr: float, momentum: float, wd: float, first: bool, stream: Optional[int] = None) -> None:
+    check(_lib.load().mla_sgd_step(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, wd, int(first),
+                                   stream or cur_stream()), "mla_sgd_step")

@@ -1,0 +1,438 @@
+"""CPU oracle for the MLA alternating-unimodal training step (TEST INFRASTRUCTURE ONLY).
+
+This file is the *checker*, never the product.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  The shipped path
+(``mla_hip``) never imports anything from ``oracle/`` and fails loudly when the HIP
+library is missing.
+
+It restates, in reference layout (NCHW activations, OIHW weights), with *explicit*
+forward and backward formulas (no autograd), the arithmetic that the reference
+triggers on the ``--gs_flag`` branch of ``main.py:419-476``:
+
+  * ResNet-18 trunk            models/backbone.py:36-52 (BasicBlock), 142-160 (ResNet.forward)
+  * pooling + flatten          models/basic_model.py:52-77 (AVClassifier.forward)
+  * shared head + CE           models/fusion_modules.py:16-19 (fc_out), main.py:130, 432-435
+  * head-gradient projection   utils/utils.py:24-41 (GSPlugin.before_update)
+  * SGD momentum + wd          main.py:749 (torch.optim.SGD), 439-440, 451-452
+  * the step orchestration     main.py:419-476
+
+Parity pin: the reference holds no golden vectors or tests, so this
+oracle is pinned against outputs of the reference's own modules run in the build
+container: ``tests/golden/make_golden.py`` imports ``/root/reference`` (models.backbone,
+models.basic_model.AVClassifier, utils.utils.GSPlugin.before_update), drives them with
+autograd + torch.optim.SGD exactly as main.py does, checks every function below against
+them and writes the fixtures under ``tests/golden/``.  ``tests/test_oracle_golden.py``
+re-checks this oracle against those fixtures without the reference present.
+
+Conv contractions use torch's CPU convolution primitives (F.conv2d and
+torch.nn.grad.conv2d_input/weight): these are the same ATen kernels the reference's
+CPU path executes, so the oracle is also the fairest CPU baseline ("port").
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# --------------------------------------------------------------------------------------
+# portable counter-based PRNG (splitmix64 + Box-Muller).  Same numbers on every machine,
+# independent of numpy/torch generator versions, so fixtures only need to hold OUTPUTS.
+# --------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def portable_uniform(seed: int, n: int, stream: int = 0) -> np.ndarray:
+    """n float64 uniforms in (0,1), a pure function of (seed, stream, index)."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([seed], dtype=np.uint64) * np.uint64(0x632BE59BD9B4E019)
+                           + np.uint64(stream) * np.uint64(0xD1342543DE82EF95))
+        idx = np.arange(n, dtype=np.uint64)
+        bits = _splitmix64(idx * np.uint64(0x2545F4914F6CDD1D) + base)
+    return ((bits >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def portable_normal(seed: int, shape, stream: int = 0, mean: float = 0.0, std: float = 1.0) -> torch.Tensor:
+    n = int(np.prod(shape))
+    m = (n + 1) // 2
+    u1 = portable_uniform(seed, m, stream * 2 + 1)
+    u2 = portable_uniform(seed, m, stream * 2 + 2)
+    r = np.sqrt(-2.0 * np.log(u1))
+    z = np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])[:n]
+    return torch.from_numpy((z * std + mean).astype(np.float32)).reshape(tuple(shape))
+
+
+def portable_labels(seed: int, n: int, n_classes: int, stream: int = 0) -> torch.Tensor:
+    u = portable_uniform(seed, n, 1000 + stream)
+    return torch.from_numpy(np.minimum((u * n_classes).astype(np.int64), n_classes - 1))
+
+
+# --------------------------------------------------------------------------------------
+# ResNet-18 parameter structure (models/backbone.py:55-140, 211-213)
+# --------------------------------------------------------------------------------------
+def resnet18_conv_specs(modality: str) -> List[Tuple[str, int, int, int, int, int]]:
+    """(state_dict prefix, cin, cout, k, stride, pad) in module order (backbone.py:78-95,118-140)."""
+    cin0 = 1 if modality == "audio" else 3
+    specs = [("conv1", cin0, 64, 7, 2, 3)]
+    inpl = 64
+    for li, planes in enumerate([64, 128, 256, 512], start=1):
+        for bi in range(2):
+            stride = 2 if (li > 1 and bi == 0) else 1
+            specs.append((f"layer{li}.{bi}.conv1", inpl, planes, 3, stride, 1))
+            specs.append((f"layer{li}.{bi}.conv2", planes, planes, 3, 1, 1))
+            if bi == 0 and (stride != 1 or inpl != planes):
+                specs.append((f"layer{li}.{bi}.downsample.0", inpl, planes, 1, stride, 0))
+            inpl = planes
+    return specs
+
+
+def bn_name_for_conv(conv_name: str) -> str:
+    if conv_name == "conv1":
+        return "bn1"
+    if conv_name.endswith("downsample.0"):
+        return conv_name[:-1] + "1"
+    return conv_name.replace("conv", "bn")
+
+
+def make_resnet18_params(modality: str, seed: int) -> Dict[str, torch.Tensor]:
+    """Portable random ResNet-18 state (reference state_dict keys, OIHW).
+
+    Distributions follow utils/utils.py:106-114 (weight_init: kaiming-normal fan_out conv,
+    BN weight 1 / bias 0), but BN affine params are jittered so that parity tests exercise
+    gamma/beta (a constant 1/0 would hide scale/shift bugs)."""
+    p: Dict[str, torch.Tensor] = {}
+    for si, (name, cin, cout, k, _s, _p) in enumerate(resnet18_conv_specs(modality)):
+        std = math.sqrt(2.0 / (cout * k * k))
+        p[name + ".weight"] = portable_normal(seed, (cout, cin, k, k), stream=10 + 4 * si, std=std)
+        bn = bn_name_for_conv(name)
+        p[bn + ".weight"] = portable_normal(seed, (cout,), stream=11 + 4 * si, mean=1.0, std=0.05)
+        p[bn + ".bias"] = portable_normal(seed, (cout,), stream=12 + 4 * si, mean=0.0, std=0.05)
+        p[bn + ".running_mean"] = torch.zeros(cout)
+        p[bn + ".running_var"] = torch.ones(cout)
+        p[bn + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    return p
+
+
+def make_head_params(d: int, c: int, seed: int) -> Dict[str, torch.Tensor]:
+    std = math.sqrt(2.0 / (d + c))  # xavier normal, utils/utils.py:107-109
+    return {"weight": portable_normal(seed, (c, d), stream=900, std=std),
+            "bias": portable_normal(seed, (c,), stream=901, std=0.01)}
+
+
+# --------------------------------------------------------------------------------------
+# primitive ops, explicit forward/backward
+# --------------------------------------------------------------------------------------
+def conv2d_fwd(x, w, stride, pad):
+    return F.conv2d(x, w, None, stride, pad)
+
+
+def conv2d_dgrad(dy, w, x_shape, stride, pad):
+    return torch.nn.grad.conv2d_input(list(x_shape), w, dy, stride=stride, padding=pad)
+
+
+def conv2d_wgrad(x, dy, w_shape, stride, pad):
+    return torch.nn.grad.conv2d_weight(x, list(w_shape), dy, stride=stride, padding=pad)
+
+
+def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None,
+                 momentum=BN_MOMENTUM, eps=BN_EPS):
+    """nn.BatchNorm2d training forward (backbone.py:29,32,86,128): biased batch variance for
+    normalisation, unbiased for the running estimate.  Returns y, mean, invstd."""
+    n = x.numel() // x.shape[1]
+    xd = x.double()
+    mean = xd.mean(dim=(0, 2, 3))
+    var = ((xd - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+    invstd = (1.0 / torch.sqrt(var + eps))
+    y = ((x - mean.float()[None, :, None, None]) * invstd.float()[None, :, None, None]
+         * gamma[None, :, None, None] + beta[None, :, None, None])
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+        running_var.mul_(1 - momentum).add_(momentum * (var * n / max(n - 1, 1)).float())
+    return y, mean.float(), invstd.float()
+
+
+def bn_train_bwd(dy, x, gamma, mean, invstd):
+    n = x.numel() // x.shape[1]
+    xhat = (x - mean[None, :, None, None]) * invstd[None, :, None, None]
+    dbeta = dy.double().sum(dim=(0, 2, 3))
+    dgamma = (dy.double() * xhat.double()).sum(dim=(0, 2, 3))
+    dx = (gamma * invstd)[None, :, None, None] * (
+        dy - (dbeta / n).float()[None, :, None, None] - xhat * (dgamma / n).float()[None, :, None, None])
+    return dx, dgamma.float(), dbeta.float()
+
+
+def maxpool3x3s2_fwd(x):
+    return F.max_pool2d(x, 3, 2, 1, return_indices=True)
+
+
+def maxpool3x3s2_bwd(dy, idx, x_shape):
+    n, c, h, w = x_shape
+    dx = torch.zeros(n, c, h * w, dtype=dy.dtype)
+    dx.scatter_add_(2, idx.reshape(n, c, -1), dy.reshape(n, c, -1))
+    return dx.reshape(n, c, h, w)
+
+
+# --------------------------------------------------------------------------------------
+# ResNet-18 trunk forward / backward  (backbone.py:142-160, 36-52)
+# --------------------------------------------------------------------------------------
+def resnet18_fwd(p: Dict[str, torch.Tensor], x: torch.Tensor, modality: str,
+                 update_running: bool = True, taps: Optional[dict] = None):
+    """Returns (feature map (N,512,h,w), cache).  `x` is (B,1,H,W) audio or (B,3,T,H,W) visual."""
+    cache: dict = {"modality": modality}
+    if modality == "visual":
+        B, C, T, H, W = x.shape
+        x = x.permute(0, 2, 1, 3, 4).contiguous().view(B * T, C, H, W)  # backbone.py:144-147
+    cache["x0"] = x
+
+    def bn(name, t):
+        rm = p[name + ".running_mean"] if update_running else None
+        rv = p[name + ".running_var"] if update_running else None
+        y, mean, invstd = bn_train_fwd(t, p[name + ".weight"], p[name + ".bias"], rm, rv)
+        if update_running:
+            p[name + ".num_batches_tracked"] += 1
+        cache[name] = (t, mean, invstd)
+        return y
+
+    y = conv2d_fwd(x, p["conv1.weight"], 2, 3)
+    y = torch.relu(bn("bn1", y))
+    cache["stem_relu"] = y
+    y, idx = maxpool3x3s2_fwd(y)
+    cache["pool_idx"] = idx
+    if taps is not None:
+        taps["stem"] = y
+    inpl = 64
+    for li, planes in enumerate([64, 128, 256, 512], start=1):
+        for bi in range(2):
+            pre = f"layer{li}.{bi}"
+            stride = 2 if (li > 1 and bi == 0) else 1
+            xin = y
+            o = conv2d_fwd(xin, p[pre + ".conv1.weight"], stride, 1)
+            o = torch.relu(bn(pre + ".bn1", o))
+            cache[pre + ".a1"] = o
+            o = conv2d_fwd(o, p[pre + ".conv2.weight"], 1, 1)
+            o = bn(pre + ".bn2", o)
+            if bi == 0 and (stride != 1 or inpl != planes):
+                idn = conv2d_fwd(xin, p[pre + ".downsample.0.weight"], stride, 0)
+                idn = bn(pre + ".downsample.1", idn)
+            else:
+                idn = xin
+            y = torch.relu(o + idn)
+            cache[pre + ".in"] = xin
+            cache[pre + ".out"] = y
+            inpl = planes
+            if taps is not None:
+                taps[pre] = y
+    return y, cache
+
+
+def resnet18_bwd(p: Dict[str, torch.Tensor], cache: dict, dout: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Explicit backward of resnet18_fwd; returns grads keyed like the state_dict."""
+    g: Dict[str, torch.Tensor] = {}
+
+    def bn_b(name, dy):
+        t, mean, invstd = cache[name]
+        dx, dgamma, dbeta = bn_train_bwd(dy, t, p[name + ".weight"], mean, invstd)
+        g[name + ".weight"] = dgamma
+        g[name + ".bias"] = dbeta
+        return dx
+
+    d = dout
+    inpls = {1: 64, 2: 64, 3: 128, 4: 256}
+    for li, planes in reversed(list(enumerate([64, 128, 256, 512], start=1))):
+        for bi in (1, 0):
+            pre = f"layer{li}.{bi}"
+            stride = 2 if (li > 1 and bi == 0) else 1
+            xin = cache[pre + ".in"]
+            out = cache[pre + ".out"]
+            a1 = cache[pre + ".a1"]
+            d = d * (out > 0)                                   # relu after the residual add
+            d_idn = d
+            dy2 = bn_b(pre + ".bn2", d)
+            w2 = p[pre + ".conv2.weight"]
+            g[pre + ".conv2.weight"] = conv2d_wgrad(a1, dy2, w2.shape, 1, 1)
+            da1 = conv2d_dgrad(dy2, w2, a1.shape, 1, 1) * (a1 > 0)
+            dy1 = bn_b(pre + ".bn1", da1)
+            w1 = p[pre + ".conv1.weight"]
+            g[pre + ".conv1.weight"] = conv2d_wgrad(xin, dy1, w1.shape, stride, 1)
+            dx = conv2d_dgrad(dy1, w1, xin.shape, stride, 1)
+            if bi == 0 and (stride != 1 or inpls[li] != planes):
+                dyd = bn_b(pre + ".downsample.1", d_idn)
+                wd = p[pre + ".downsample.0.weight"]
+                g[pre + ".downsample.0.weight"] = conv2d_wgrad(xin, dyd, wd.shape, stride, 0)
+                dx = dx + conv2d_dgrad(dyd, wd, xin.shape, stride, 0)
+            else:
+                dx = dx + d_idn
+            d = dx
+    d = maxpool3x3s2_bwd(d, cache["pool_idx"], cache["stem_relu"].shape)
+    d = d * (cache["stem_relu"] > 0)
+    dy = bn_b("bn1", d)
+    g["conv1.weight"] = conv2d_wgrad(cache["x0"], dy, p["conv1.weight"].shape, 2, 3)
+    return g
+
+
+# --------------------------------------------------------------------------------------
+# AVClassifier pooling (basic_model.py:56-65)
+# --------------------------------------------------------------------------------------
+def av_pool_fwd(fa: torch.Tensor, fv: torch.Tensor, batch: int):
+    a = fa.mean(dim=(2, 3))                                      # adaptive_avg_pool2d(a,1)+flatten
+    _, C, H, W = fv.shape
+    v = fv.view(batch, -1, C, H, W).permute(0, 2, 1, 3, 4)        # (B,C,T,H,W)
+    v = v.mean(dim=(2, 3, 4))                                     # adaptive_avg_pool3d(v,1)+flatten
+    return a, v
+
+
+def audio_pool_bwd(da: torch.Tensor, fa_shape):
+    n, c, h, w = fa_shape
+    return (da / (h * w))[:, :, None, None].expand(n, c, h, w).contiguous()
+
+
+def visual_pool_bwd(dv: torch.Tensor, fv_shape, batch: int):
+    nt, c, h, w = fv_shape
+    t = nt // batch
+    return (dv / (t * h * w))[:, None, :, None, None].expand(batch, t, c, h, w).reshape(nt, c, h, w).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# shared head + cross entropy (fusion_modules.py:16-19; main.py:130,432-435)
+# --------------------------------------------------------------------------------------
+def head_ce_fwd_bwd(X: torch.Tensor, W: torch.Tensor, b: torch.Tensor, labels: torch.Tensor):
+    """logits = X W^T + b; mean CE; returns logits, loss, dW, db, dX."""
+    B = X.shape[0]
+    logits = X @ W.t() + b
+    m = logits.max(dim=1, keepdim=True).values
+    e = torch.exp(logits - m)
+    s = e.sum(dim=1, keepdim=True)
+    logp = logits - m - torch.log(s)
+    loss = -logp[torch.arange(B), labels].mean()
+    dl = e / s
+    dl[torch.arange(B), labels] -= 1.0
+    dl = dl / B
+    return logits, loss, dl.t() @ X, dl.sum(dim=0), dl @ W
+
+
+# --------------------------------------------------------------------------------------
+# GSPlugin.before_update (utils/utils.py:24-41), literal, incl. quirks Q1/Q2/Q5 of SURVEY.md
+# --------------------------------------------------------------------------------------
+def gs_alpha(batch_index: int, len_dataloader: int) -> float:
+    lamda = batch_index / len_dataloader + 1        # utils/utils.py:26
+    return 1.0 * 0.1 ** lamda                       # utils/utils.py:27
+
+
+def gs_before_update(Pl: torch.Tensor, X: torch.Tensor, G: torch.Tensor, batch_index: int,
+                     len_dataloader: int, train_exp_counter: int, mode: str = "as_intended"):
+    """Returns (Pl_new, G_new).  mode 'as_published' reproduces the name-mismatch no-op (Q1);
+    'as_intended' executes utils/utils.py:34-41 (element-wise DxD denominator, Frobenius renorm)."""
+    if mode == "as_published" or train_exp_counter == 0:
+        return Pl, G
+    alpha = gs_alpha(batch_index, len_dataloader)
+    r = X.mean(dim=0, keepdim=True)                              # (1,D)          :34
+    k = Pl @ r.t()                                               # (D,1)          :35
+    Pl = Pl - (k @ k.t()) / (alpha + k @ r)                      # element-wise   :36
+    Pl = Pl / torch.linalg.norm(Pl)                              # Frobenius      :38-40
+    return Pl, G @ Pl.t()                                        #                :41
+
+
+# --------------------------------------------------------------------------------------
+# SGD with momentum + weight decay (main.py:749)
+# --------------------------------------------------------------------------------------
+def sgd_step(p: torch.Tensor, g: Optional[torch.Tensor], buf: Optional[torch.Tensor],
+             lr: float, momentum: float = 0.9, wd: float = 1e-4):
+    """torch.optim.SGD semantics (dampening 0, no nesterov).  g None -> zero gradient
+    (legacy torch-1.8.1 zero_grad behaviour).  Returns (p_new, buf_new)."""
+    g = torch.zeros_like(p) if g is None else g
+    d = g + wd * p
+    buf = d.clone() if buf is None else momentum * buf + d
+    return p - lr * buf, buf
+
+
+# --------------------------------------------------------------------------------------
+# the MLA alternating step (main.py:419-476) over a functional state
+# --------------------------------------------------------------------------------------
+class MLAState:
+    """Everything the step mutates: encoder params + BN buffers, head, momentum, Pl, exp_count."""
+
+    def __init__(self, audio: Dict[str, torch.Tensor], visual: Dict[str, torch.Tensor],
+                 head: Dict[str, torch.Tensor], d: int = 512):
+        self.audio, self.visual, self.head = audio, visual, head
+        self.mom: Dict[str, Dict[str, Optional[torch.Tensor]]] = {"audio": {}, "visual": {}, "head": {}}
+        self.Pl = torch.eye(d)
+        self.exp_count = 0
+
+    def clone(self) -> "MLAState":
+        s = MLAState({k: v.clone() for k, v in self.audio.items()},
+                     {k: v.clone() for k, v in self.visual.items()},
+                     {k: v.clone() for k, v in self.head.items()}, self.Pl.shape[0])
+        s.mom = {m: {k: (None if v is None else v.clone()) for k, v in d.items()} for m, d in self.mom.items()}
+        s.Pl = self.Pl.clone()
+        s.exp_count = self.exp_count
+        return s
+
+
+def _is_param(k: str) -> bool:
+    return not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))
+
+
+def _sgd_group(params: Dict[str, torch.Tensor], grads: Optional[Dict[str, torch.Tensor]],
+               mom: Dict[str, Optional[torch.Tensor]], lr, momentum, wd):
+    for k in list(params.keys()):
+        if not _is_param(k):
+            continue
+        g = None if grads is None else grads[k]
+        params[k], mom[k] = sgd_step(params[k], g, mom.get(k), lr, momentum, wd)
+
+
+def mla_step(st: MLAState, spec: torch.Tensor, image: torch.Tensor, label: torch.Tensor,
+             batch_index: int, len_dataloader: int, lr: float = 1e-3, momentum: float = 0.9,
+             wd: float = 1e-4, gs_mode: str = "as_intended", legacy_zero_grad: bool = False,
+             av_alpha: float = 0.55) -> dict:
+    """One pass of main.py:419-476 (ResNet/CREMA-D branch).  spec (B,H,W) or (B,1,H,W); image (B,3,T,H,W)."""
+    out: dict = {}
+    B = spec.shape[0]
+    if spec.dim() == 3:
+        spec = spec.unsqueeze(1)                                  # main.py:431
+    fa, ca = resnet18_fwd(st.audio, spec.float(), "audio")
+    fv, cv = resnet18_fwd(st.visual, image.float(), "visual")
+    a, v = av_pool_fwd(fa, fv, B)
+    out["a"], out["v"] = a, v
+
+    # ---- audio phase (main.py:432-442)
+    W, b = st.head["weight"], st.head["bias"]
+    logits, loss, dW, db, dX = head_ce_fwd_bwd(a, W, b, label)
+    out["out_a"], out["loss_a"], out["head_grad_a_raw"] = logits, loss, dW.clone()
+    ga = resnet18_bwd(st.audio, ca, audio_pool_bwd(dX, fa.shape))
+    st.Pl, dW = gs_before_update(st.Pl, a, dW, batch_index, len_dataloader, st.exp_count, gs_mode)
+    out["head_grad_a"], out["grads_audio"] = dW, ga
+    _sgd_group(st.audio, ga, st.mom["audio"], lr, momentum, wd)
+    _sgd_group(st.head, {"weight": dW, "bias": db}, st.mom["head"], lr, momentum, wd)
+    st.exp_count += 1
+
+    # ---- visual phase (main.py:444-454); uses the head already updated by the audio step (Q7)
+    W, b = st.head["weight"], st.head["bias"]
+    logits, loss_v, dW, db, dX = head_ce_fwd_bwd(v, W, b, label)
+    out["out_v"], out["loss_v"], out["head_grad_v_raw"] = logits, loss_v, dW.clone()
+    gv = resnet18_bwd(st.visual, cv, visual_pool_bwd(dX, fv.shape, B))
+    st.Pl, dW = gs_before_update(st.Pl, v, dW, batch_index, len_dataloader, st.exp_count, gs_mode)
+    out["head_grad_v"], out["grads_visual"] = dW, gv
+    if legacy_zero_grad:                                          # torch 1.8.1: zeroed, not None (Q6)
+        _sgd_group(st.audio, None, st.mom["audio"], lr, momentum, wd)
+    _sgd_group(st.visual, gv, st.mom["visual"], lr, momentum, wd)
+    _sgd_group(st.head, {"weight": dW, "bias": db}, st.mom["head"], lr, momentum, wd)
+    st.exp_count += 1
+
+    out["loss"] = loss * av_alpha + loss_v * (1 - av_alpha)      # main.py:472 (Q8)
+    return out

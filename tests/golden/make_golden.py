@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference, read-only).  It imports the
+reference's `models.backbone`, `models.basic_model.AVClassifier`, `models.fusion_modules`
+and `utils.utils.GSPlugin` unmodified (inert `sys.modules` stand-ins for the absent,
+never-called `timm` / `ml_collections` / `torchvision` packages that `models/basic_model.py` imports at
+module scope), drives them exactly as `main.py:419-476` does -- autograd `backward()`,
+`torch.optim.SGD(momentum=0.9, weight_decay=1e-4)`, `GSPlugin.before_update` -- on inputs and
+weights from the portable PRNG in `oracle/mla_oracle.py`, and
+
+  1. asserts that every function of the oracle agrees with the reference on those runs,
+  2. writes the reference's OUTPUTS as .npz fixtures (data only; no reference source text).
+
+The fixtures are what `tests/test_oracle_golden.py` (CPU) and the GPU parity tests check
+against when /root/reference is not present (the GPU box).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import mla_oracle as O  # noqa: E402
+
+
+def _install_stubs():
+    """Inert stand-ins for packages imported (never called on this path) by models/basic_model.py."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:  # placeholder class objects so `from x import Y` succeeds
+        def __init__(self, *a, **k):
+            raise RuntimeError("stub: not available offline")
+
+    class ConfigDict(dict):
+        __getattr__ = dict.get
+        __setattr__ = dict.__setitem__
+
+        def copy_and_resolve_references(self):
+            return ConfigDict(self)
+
+    if "timm" not in sys.modules:
+        mod("timm")
+        mod("timm.models")
+        mod("timm.models.layers", to_2tuple=lambda x: (x, x), trunc_normal_=None, DropPath=_Dummy)
+        mod("timm.models.vision_transformer", Attention=_Dummy, Mlp=_Dummy, PatchEmbed=_Dummy, Block=_Dummy)
+    if "torchvision" not in sys.modules:
+        mod("torchvision", transforms=mod("torchvision.transforms"))
+    if "ml_collections" not in sys.modules:
+        mod("ml_collections", ConfigDict=ConfigDict)
+        mod("ml_collections.config_dict", ConfigDict=ConfigDict, config_dict=types.SimpleNamespace(placeholder=lambda t: None))
+
+
+import transformers  # noqa: E402,F401  real package; must be imported BEFORE the stubs (it probes __spec__)
+
+_install_stubs()
+from models.basic_model import AVClassifier  # noqa: E402  (reference)
+from utils.utils import GSPlugin  # noqa: E402  (reference)
+
+
+class _Args:
+    fusion_method = "concat"
+    dataset = "CREMAD"
+    gs_flag = True
+    modulation = "Normal"
+
+
+class _Wrap(nn.Module):
+    """Exposes fc_out as attribute `module`, so named_parameters() yields 'module.weight'
+    and utils/utils.py:32-41 executes untouched ('as_intended')."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+
+def build_reference(seed):
+    model = AVClassifier(_Args())
+    pa, pv = O.make_resnet18_params("audio", seed), O.make_resnet18_params("visual", seed + 1)
+    hd = O.make_head_params(512, 6, seed + 2)
+    model.audio_net.load_state_dict(pa)
+    model.visual_net.load_state_dict(pv)
+    model.fusion_module.fc_out.load_state_dict(hd)
+    return torch.nn.DataParallel(model), pa, pv, hd
+
+
+def reference_step(model, optimizer, gs, spec, image, label, batch_step, len_dataloader,
+                   gs_mode, legacy):
+    """main.py:419-476 restated around the imported reference modules."""
+    rec = {}
+    model.train()
+    optimizer.zero_grad()                                                   # main.py:164
+    a, v = model(spec.unsqueeze(1).float(), image.float())                  # :431
+    fc = model.module.fusion_module.fc_out
+    target = _Wrap(fc) if gs_mode == "as_intended" else fc
+    crit = nn.CrossEntropyLoss()
+    rec["a"], rec["v"] = a.detach().clone(), v.detach().clone()
+    for name, feat in (("a", a), ("v", v)):
+        out = fc(feat)                                                      # :432 / :444
+        loss = crit(out, label)
+        loss.backward()                                                     # :435 / :447
+        rec["out_" + name], rec["loss_" + name] = out.detach().clone(), loss.detach().clone()
+        rec[f"head_grad_{name}_raw"] = fc.weight.grad.detach().clone()
+        rec[f"head_bias_grad_{name}"] = fc.bias.grad.detach().clone()
+        net = model.module.audio_net if name == "a" else model.module.visual_net
+        rec["grads_" + ("audio" if name == "a" else "visual")] = {
+            k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        gs.before_update(target, feat, batch_step, len_dataloader, gs.exp_count)   # :437 / :449
+        rec[f"head_grad_{name}"] = fc.weight.grad.detach().clone()
+        optimizer.step()                                                    # :439 / :451
+        if legacy:
+            optimizer.zero_grad(set_to_none=False)                          # torch 1.8.1 semantics (Q6)
+        else:
+            optimizer.zero_grad()
+        gs.exp_count += 1
+    for _n, p in model.named_parameters():                                  # :468-470
+        if p.grad is not None:
+            del p.grad
+    rec["loss"] = (rec["loss_a"] * 0.55 + rec["loss_v"] * 0.45)             # :472 (Q8)
+    return rec
+
+
+def close(name, got, want, rtol=2e-4, atol=2e-6):
+    got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    ok = err <= atol + rtol * ref
+    print(f"  {'ok ' if ok else 'BAD'} {name:40s} max|d|={err:.3e} max|ref|={ref:.3e}")
+    assert ok, name
+    return err
+
+
+def close_l2(name, got, want, tol=3e-3):
+    """Norm-wise check for encoder gradients/weights: a single ReLU / max-pool decision that flips
+    under 1e-7 weight differences moves isolated elements by a discrete amount, so element-wise
+    max error is not meaningful there; the relative L2 error is."""
+    got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
+    err = torch.linalg.norm((got - want).flatten()).item()
+    ref = torch.linalg.norm(want.flatten()).item()
+    ok = err <= tol * ref + 1e-12
+    print(f"  {'ok ' if ok else 'BAD'} {name:40s} relL2={err / max(ref, 1e-30):.3e}")
+    assert ok, name
+
+
+def pl_digest(Pl):
+    Pl = Pl.detach()
+    return {"fro": torch.linalg.norm(Pl).item(), "trace": torch.trace(Pl).item(),
+            "corner": Pl[:8, :8].clone().numpy(), "sub": Pl[::16, ::16].clone().numpy(),
+            "rowsum": Pl.sum(1).numpy()}
+
+
+def run_case(tag, B, spec_hw, T, img_hw, steps, gs_mode, legacy, seed, len_dataloader=10, keep_grads=()):
+    print(f"== case {tag}: B={B} spec={spec_hw} T={T} img={img_hw} steps={steps} gs={gs_mode} legacy={legacy}")
+    torch.manual_seed(0)
+    model, pa, pv, hd = build_reference(seed)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)   # main.py:749
+    gs = GSPlugin.__new__(GSPlugin)          # ctor needs a GPU (Q3); state set by hand
+    gs.Pl = torch.eye(512)
+    gs.exp_count = 0
+    st = O.MLAState({k: v.clone() for k, v in pa.items()}, {k: v.clone() for k, v in pv.items()},
+                    {k: v.clone() for k, v in hd.items()})
+    fx = {}
+    for s in range(steps):
+        spec = O.portable_normal(seed + 100 + s, (B,) + spec_hw, stream=1, mean=-5.081, std=4.4849)
+        image = O.portable_normal(seed + 100 + s, (B, 3, T) + img_hw, stream=2)
+        label = O.portable_labels(seed + 100 + s, B, 6)
+        ref = reference_step(model, opt, gs, spec, image, label, s, len_dataloader, gs_mode, legacy)
+        orc = O.mla_step(st, spec, image, label, s, len_dataloader, gs_mode=gs_mode, legacy_zero_grad=legacy)
+        for k in ("a", "v", "out_a", "out_v", "loss_a", "loss_v", "loss", "head_grad_a_raw",
+                  "head_grad_v_raw", "head_grad_a", "head_grad_v"):
+            close(f"s{s}.{k}", orc[k], ref[k])
+            fx[f"s{s}.{k}"] = ref[k].numpy()
+        for enc in ("audio", "visual"):
+            for k, gref in ref["grads_" + enc].items():
+                close_l2(f"s{s}.grad.{enc}.{k}", orc["grads_" + enc][k], gref)
+            for k in keep_grads:
+                gref = ref["grads_" + enc][k]
+                fx[f"s{s}.grad.{enc}.{k}.sum"] = np.float64(gref.double().sum().item())
+                fx[f"s{s}.grad.{enc}.{k}.abssum"] = np.float64(gref.double().abs().sum().item())
+                fx[f"s{s}.grad.{enc}.{k}.head"] = gref.flatten()[:64].numpy()
+        # post-step state
+        sd = model.module.state_dict()
+        for enc, params in (("audio_net", st.audio), ("visual_net", st.visual)):
+            for k, vv in params.items():
+                close_l2(f"s{s}.state.{enc}.{k}", vv, sd[f"{enc}.{k}"], tol=1e-4)
+        close(f"s{s}.state.head.weight", st.head["weight"], sd["fusion_module.fc_out.weight"])
+        close(f"s{s}.state.head.bias", st.head["bias"], sd["fusion_module.fc_out.bias"])
+        close(f"s{s}.Pl", st.Pl, gs.Pl.detach(), rtol=1e-4, atol=1e-7)
+        fx[f"s{s}.head.weight"] = sd["fusion_module.fc_out.weight"].numpy().copy()
+        fx[f"s{s}.head.bias"] = sd["fusion_module.fc_out.bias"].numpy().copy()
+        for enc in ("audio_net", "visual_net"):
+            fx[f"s{s}.{enc}.bn1.running_mean"] = sd[f"{enc}.bn1.running_mean"].numpy().copy()
+            fx[f"s{s}.{enc}.bn1.running_var"] = sd[f"{enc}.bn1.running_var"].numpy().copy()
+            fx[f"s{s}.{enc}.conv1.weight"] = sd[f"{enc}.conv1.weight"].numpy().copy()
+            w = sd[f"{enc}.layer4.1.conv2.weight"]
+            fx[f"s{s}.{enc}.layer4.1.conv2.weight.sum"] = np.float64(w.double().sum().item())
+            fx[f"s{s}.{enc}.layer4.1.conv2.weight.head"] = w.flatten()[:64].numpy().copy()
+        for k, vv in pl_digest(gs.Pl).items():
+            fx[f"s{s}.Pl.{k}"] = np.asarray(vv)
+    fx["meta"] = np.array([B, spec_hw[0], spec_hw[1], T, img_hw[0], img_hw[1], steps, seed, len_dataloader], dtype=np.int64)
+    fx["gs_mode"] = np.array(gs_mode)
+    fx["legacy"] = np.array(int(legacy))
+    path = os.path.join(HERE, f"mla_{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def run_gs_kat(D, C, B, calls, seed):
+    """Known-answer trajectory of GSPlugin.before_update alone (utils/utils.py:24-41), D=512 and 768."""
+    print(f"== gs KAT D={D} C={C} B={B} calls={calls}")
+    fc = nn.Linear(D, C)
+    gs = GSPlugin.__new__(GSPlugin)
+    gs.Pl = torch.eye(D)
+    gs.exp_count = 0
+    Pl = torch.eye(D)
+    fx = {}
+    for i in range(calls):
+        X = O.portable_normal(seed + i, (B, D), stream=5, mean=0.3, std=0.7).abs()   # pooled relu features are >= 0
+        G = O.portable_normal(seed + i, (C, D), stream=6, std=0.05)
+        fc.weight.grad = G.clone()
+        gs.before_update(_Wrap(fc), X, i % 7, 7, gs.exp_count)
+        gs.exp_count += 1
+        Pl, Gp = O.gs_before_update(Pl, X, G, i % 7, 7, i, "as_intended")
+        close(f"gs{i}.G", Gp, fc.weight.grad, rtol=1e-4, atol=1e-8)
+        close(f"gs{i}.Pl", Pl, gs.Pl.detach(), rtol=1e-4, atol=1e-8)
+        fx[f"c{i}.G"] = fc.weight.grad.detach().numpy().copy()
+        for k, vv in pl_digest(gs.Pl).items():
+            fx[f"c{i}.Pl.{k}"] = np.asarray(vv)
+    fx["meta"] = np.array([D, C, B, calls, seed], dtype=np.int64)
+    path = os.path.join(HERE, f"gs_kat_d{D}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    keep = ("conv1.weight", "bn1.weight", "bn1.bias", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight",
+            "layer2.0.conv1.weight", "layer4.1.conv2.weight", "layer4.1.bn2.weight")
+    run_case("small_intended", 4, (128, 64), 2, (96, 96), 2, "as_intended", False, seed=7, keep_grads=keep)
+    run_case("small_published", 4, (128, 64), 2, (96, 96), 2, "as_published", False, seed=7, keep_grads=keep)
+    run_case("small_legacy", 4, (128, 64), 2, (96, 96), 2, "as_intended", True, seed=7, keep_grads=keep)
+    run_case("full_b2", 2, (1024, 128), 3, (224, 224), 1, "as_intended", False, seed=11, keep_grads=keep)
+    run_gs_kat(512, 6, 64, 5, seed=21)
+    run_gs_kat(768, 101, 64, 3, seed=23)
+    print("all oracle-vs-reference checks passed")

@@ -1,0 +1,280 @@
+"""Per-kernel parity: HIP (through the C ABI) vs the CPU oracle, same seeded inputs.
+
+fp32 everywhere.  Tolerances: conv contractions 2e-5 relative to max|ref| (fp32 MFMA is an exact
+k-ordered fmaf chain; only the summation order differs from ATen's), BN/pool/head/GS/SGD 1e-5.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mla_oracle as O  # noqa: E402
+from util import assert_close  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mla_hip import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def hwio(w):
+    return w.permute(2, 3, 1, 0).contiguous()
+
+
+def oihw(w):
+    return w.permute(3, 2, 0, 1).contiguous()
+
+
+# every conv configuration of ResNet-18 (backbone.py) at reduced spatial size, plus ragged sizes
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 40, 24, 1, 64, 7, 2, 3),      # audio stem
+    (3, 36, 36, 3, 64, 7, 2, 3),      # visual stem
+    (2, 20, 12, 64, 64, 3, 1, 1),     # layer1
+    (2, 20, 12, 64, 128, 3, 2, 1),    # layer2.0.conv1
+    (2, 20, 12, 64, 128, 1, 2, 0),    # layer2.0.downsample
+    (2, 10, 6, 128, 128, 3, 1, 1),
+    (3, 14, 14, 128, 256, 3, 2, 1),   # 14 -> 7 (odd output)
+    (3, 14, 14, 128, 256, 1, 2, 0),
+    (3, 7, 7, 256, 256, 3, 1, 1),
+    (3, 7, 7, 256, 512, 3, 2, 1),     # odd input
+    (3, 7, 7, 256, 512, 1, 2, 0),
+    (2, 4, 4, 512, 512, 3, 1, 1),
+    (1, 5, 3, 64, 64, 3, 1, 1),       # tiny / ragged: M=15 << tile
+    (5, 9, 11, 64, 128, 3, 2, 1),     # odd everything
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    N, H, W, Cin, Cout, k, s, p = case
+    seed = sum(case)
+    x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
+    w = O.portable_normal(seed, (Cout, Cin, k, k), stream=2, std=math.sqrt(2.0 / (Cin * k * k)))
+    y_ref = O.conv2d_fwd(x, w, s, p)
+    dy = O.portable_normal(seed, tuple(y_ref.shape), stream=3)
+    xd, wd, dyd = nhwc(x).cuda(), hwio(w).cuda(), nhwc(dy).cuda()
+
+    # forward + fused BN partial statistics
+    part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, k, k, s, p), device="cuda")
+    y, tiles = ops.conv2d_fwd(xd, wd, s, p, bn_partial=part)
+    assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="conv fwd")
+    pt = part.view(tiles, 2, Cout).double().sum(0).cpu()
+    assert_close(pt[0], y_ref.double().sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="fused colsum")
+    assert_close(pt[1], (y_ref.double() ** 2).sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="fused colsumsq")
+
+    # weight gradient
+    dw_ref = O.conv2d_wgrad(x, dy, w.shape, s, p)
+    ws = torch.empty(ops.conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, k, k, s, p) // 4 + 4, device="cuda")
+    dw = torch.empty_like(wd)
+    ops.conv2d_wgrad(xd, dyd, dw, s, p, ws)
+    assert_close(oihw(dw.cpu()), dw_ref, atol=0, rtol=2e-5, name="conv wgrad")
+
+    # input gradient (+ residual + relu mask epilogue); the stem needs none
+    if Cin % 64 == 0:
+        dx_ref = O.conv2d_dgrad(dy, w, x.shape, s, p)
+        wt_ws = torch.empty(w.numel(), device="cuda")
+        dx = ops.conv2d_dgrad(dyd, wd, (N, H, W, Cin), s, p, wt_ws)
+        assert_close(nchw(dx.cpu()), dx_ref, atol=0, rtol=2e-5, name="conv dgrad")
+        res = O.portable_normal(seed, (N, Cin, H, W), stream=4)
+        msk = O.portable_normal(seed, (N, Cin, H, W), stream=5)
+        dx2 = torch.empty_like(dx)
+        ops.conv2d_dgrad(dyd, wd, (N, H, W, Cin), s, p, wt_ws, dx=dx2, residual=nhwc(res).cuda(), relu_src=nhwc(msk).cuda())
+        assert_close(nchw(dx2.cpu()), (dx_ref + res) * (msk > 0), atol=0, rtol=2e-5, name="conv dgrad+res+mask")
+        # accumulate in place (residual aliases dx)
+        ops.conv2d_dgrad(dyd, wd, (N, H, W, Cin), s, p, wt_ws, dx=dx, residual=dx)
+        assert_close(nchw(dx.cpu()), 2 * dx_ref, atol=0, rtol=2e-5, name="conv dgrad accumulate")
+
+
+def test_conv_rejects_bad_shapes(ops):
+    from mla_hip import MLAHipError
+    x = torch.zeros((1, 8, 8, 48), device="cuda")
+    w = torch.zeros((3, 3, 48, 64), device="cuda")
+    with pytest.raises(MLAHipError):
+        ops.conv2d_fwd(x, w, 1, 1)                      # Cin not a multiple of 64 and > 4
+    with pytest.raises(MLAHipError):
+        ops.conv2d_fwd(torch.zeros((1, 8, 8, 64), device="cuda"), torch.zeros((3, 3, 64, 64), device="cuda"), 3, 1)
+    with pytest.raises(MLAHipError):
+        ops.conv2d_fwd(x.cpu(), w, 1, 1)                # host tensor
+
+
+@pytest.mark.parametrize("M,C", [(1000, 64), (37, 128), (4096, 256), (300, 512), (70000, 64)])
+def test_bn_fwd_bwd(ops, M, C):
+    # treat as N=1, H=M, W=1
+    x = O.portable_normal(M + C, (1, C, M, 1), stream=1, mean=0.7, std=1.8)
+    gamma = O.portable_normal(M + C, (C,), stream=2, mean=1.0, std=0.2)
+    beta = O.portable_normal(M + C, (C,), stream=3, std=0.3)
+    res = O.portable_normal(M + C, (1, C, M, 1), stream=4)
+    rm, rv = torch.zeros(C) + 0.25, torch.ones(C) * 1.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref, mean_ref, invstd_ref = O.bn_train_fwd(x, gamma, beta, rm_ref, rv_ref)
+    out_ref = torch.relu(y_ref + res)
+
+    xd = nhwc(x).cuda().view(M, C)
+    part = torch.empty(ops.bn_stats_partial_elems(M, C), device="cuda")
+    tiles = ops.bn_stats_partial(xd, M, C, part)
+    mean, invstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rmd, rvd = rm.cuda(), rv.cuda()
+    ops.bn_finalize(part, tiles, M, C, mean, invstd, rmd, rvd)
+    assert_close(mean, mean_ref, atol=1e-6, rtol=1e-5, name="bn mean")
+    assert_close(invstd, invstd_ref, atol=0, rtol=1e-5, name="bn invstd")
+    assert_close(rmd, rm_ref, atol=1e-6, rtol=1e-5, name="running_mean")
+    assert_close(rvd, rv_ref, atol=0, rtol=1e-5, name="running_var")
+    out = torch.empty((M, C), device="cuda")
+    ops.bn_apply(xd, mean, invstd, gamma.cuda(), beta.cuda(), out, M, C, True, residual=nhwc(res).cuda().view(M, C))
+    assert_close(out.cpu(), nhwc(out_ref).view(M, C), atol=1e-5, rtol=1e-5, name="bn apply+res+relu")
+
+    # backward with relu mask and residual-branch gradient output
+    dout = O.portable_normal(M + C, (1, C, M, 1), stream=5)
+    g_ref = dout * (out_ref > 0)
+    dx_ref, dgamma_ref, dbeta_ref = O.bn_train_bwd(g_ref, x, gamma, mean_ref, invstd_ref)
+    dx, g_out = torch.empty((M, C), device="cuda"), torch.empty((M, C), device="cuda")
+    dgamma, dbeta = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ws = torch.empty(ops.bn_bwd_ws_elems(M, C), device="cuda")
+    ops.bn_bwd(nhwc(dout).cuda().view(M, C), xd, mean, invstd, gamma.cuda(), dx, dgamma, dbeta, ws, M, C, relu_out=out, g_out=g_out)
+    assert_close(g_out.cpu(), nhwc(g_ref).view(M, C), atol=1e-6, name="bn bwd g")
+    assert_close(dgamma, dgamma_ref, atol=1e-4, rtol=2e-5, name="dgamma")
+    assert_close(dbeta, dbeta_ref, atol=1e-4, rtol=2e-5, name="dbeta")
+    assert_close(dx.cpu(), nhwc(dx_ref).view(M, C), atol=1e-6, rtol=2e-5, name="bn dx")
+    # in place (dx aliases dout), no mask
+    d2 = nhwc(dout).cuda().view(M, C).clone()
+    ops.bn_bwd(d2, xd, mean, invstd, gamma.cuda(), d2, dgamma, dbeta, ws, M, C)
+    dx_ref2, _, _ = O.bn_train_bwd(dout, x, gamma, mean_ref, invstd_ref)
+    assert_close(d2.cpu(), nhwc(dx_ref2).view(M, C), atol=1e-6, rtol=2e-5, name="bn dx in place")
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 12, 64), (3, 9, 7, 64), (1, 2, 2, 128)])
+def test_maxpool(ops, N, H, W, C):
+    x = torch.relu(O.portable_normal(N * H + W, (N, C, H, W), stream=1))       # many exact-zero ties, like the stem
+    y_ref, idx_ref = O.maxpool3x3s2_fwd(x)
+    OH, OW = y_ref.shape[2:]
+    y = torch.empty((N, OH, OW, C), device="cuda")
+    idx = torch.empty((N, OH, OW, C), device="cuda", dtype=torch.uint8)
+    xd = nhwc(x).cuda()
+    ops.maxpool_fwd(xd, y, idx)
+    assert_close(nchw(y.cpu()), y_ref, atol=0, name="maxpool fwd")           # bit exact
+    dy = O.portable_normal(N * H + W, tuple(y_ref.shape), stream=2)
+    dx_ref = O.maxpool3x3s2_bwd(dy, idx_ref, x.shape) * (x > 0)
+    dx = torch.empty((N, H, W, C), device="cuda")
+    ops.maxpool_bwd(nhwc(dy).cuda(), idx, dx, (N, H, W, C), relu_src=xd)
+    assert_close(nchw(dx.cpu()), dx_ref, atol=1e-6, name="maxpool bwd (+relu mask)")
+    # without the mask the tie-breaking itself must match ATen (first maximum in window order)
+    ops.maxpool_bwd(nhwc(dy).cuda(), idx, dx, (N, H, W, C))
+    assert_close(nchw(dx.cpu()), O.maxpool3x3s2_bwd(dy, idx_ref, x.shape), atol=1e-6, name="maxpool bwd ties")
+
+
+@pytest.mark.parametrize("B,T,h,w,C", [(4, 1, 32, 4, 512), (4, 3, 7, 7, 512), (3, 2, 1, 1, 512), (2, 1, 5, 3, 64)])
+def test_avgpool(ops, B, T, h, w, C):
+    f = torch.relu(O.portable_normal(B + T + h, (B * T, C, h, w), stream=1))
+    if T == 1:
+        ref = f.mean(dim=(2, 3))
+    else:
+        _, ref = O.av_pool_fwd(f[:B], f, B)
+    fd = nhwc(f).cuda()
+    y = torch.empty((B, C), device="cuda")
+    ops.avgpool_fwd(fd, y, B, T * h * w, C)
+    assert_close(y, ref, atol=1e-6, rtol=1e-6, name="avgpool fwd")
+    dy = O.portable_normal(B + T + h, (B, C), stream=2)
+    dref = (O.visual_pool_bwd(dy, f.shape, B) if T > 1 else O.audio_pool_bwd(dy, f.shape)) * (f > 0)
+    dx = torch.empty_like(fd)
+    ops.avgpool_bwd(dy.cuda(), dx, B, T * h * w, C, relu_src=fd)
+    assert_close(nchw(dx.cpu()), dref, atol=1e-7, rtol=1e-6, name="avgpool bwd")
+
+
+def test_video_to_nhwc_and_transposes(ops):
+    v = O.portable_normal(3, (2, 3, 3, 10, 6), stream=1)
+    got = ops.video_to_nhwc(v.cuda()).cpu()
+    want = v.permute(0, 2, 1, 3, 4).contiguous().view(6, 3, 10, 6).permute(0, 2, 3, 1)
+    assert torch.equal(got, want.contiguous())
+    t = O.portable_normal(4, (3, 70, 9, 5), stream=1)
+    assert torch.equal(ops.nchw_to_nhwc(t.cuda()).cpu(), nhwc(t))
+    assert torch.equal(ops.nhwc_to_nchw(nhwc(t).cuda()).cpu(), t)
+
+
+@pytest.mark.parametrize("B,D,C", [(64, 512, 6), (8, 512, 6), (5, 768, 101), (32, 768, 4), (1, 512, 6)])
+def test_head_ce(ops, B, D, C):
+    X = torch.relu(O.portable_normal(B + C, (B, D), stream=1, mean=0.3))
+    hd = O.make_head_params(D, C, seed=B)
+    labels = O.portable_labels(B + C, B, C)
+    inv = 1.0 / (2 * B)                                                         # e.g. world size 2
+    logits_r, loss_r, dW_r, db_r, dX_r = O.head_ce_fwd_bwd(X, hd["weight"], hd["bias"], labels)
+    scale = B * inv
+    f = lambda *s: torch.empty(s, device="cuda")
+    logits, loss, dW, db, dX = f(B, C), f(1), f(C, D), f(C), f(B, D)
+    ws = f(ops.head_ws_elems(B, C))
+    ops.head_ce_fwd_bwd(X.cuda(), hd["weight"].cuda(), hd["bias"].cuda(), labels.cuda(), logits, loss, dW, db, dX, ws, inv)
+    assert_close(logits, logits_r, atol=2e-6, rtol=2e-6, name="logits")
+    assert_close(loss, (loss_r * scale).reshape(1), atol=2e-6, rtol=2e-6, name="loss")
+    assert_close(dW, dW_r * scale, atol=1e-7, rtol=1e-5, name="dW")
+    assert_close(db, db_r * scale, atol=1e-7, rtol=1e-5, name="db")
+    assert_close(dX, dX_r * scale, atol=1e-8, rtol=1e-5, name="dX")
+
+
+@pytest.mark.parametrize("D", [512, 768])
+def test_gs_project_golden(ops, D, golden_dir):
+    """GSPlugin.before_update trajectory vs the REFERENCE's own outputs (tests/golden/gs_kat_d*.npz)."""
+    import numpy as np
+    import os
+    from mla_hip import GSPlugin, SharedHead
+    fx = np.load(os.path.join(golden_dir, f"gs_kat_d{D}.npz"))
+    D_, C, B, calls, seed = [int(v) for v in fx["meta"]]
+    head = SharedHead(D, C, seed=0)
+    gs = GSPlugin(dim=D)
+    for i in range(calls):
+        X = O.portable_normal(seed + i, (B, D), stream=5, mean=0.3, std=0.7).abs()
+        G = O.portable_normal(seed + i, (C, D), stream=6, std=0.05)
+        head.weight_grad.copy_(G)
+        gs.before_update(head, X.cuda(), i % 7, 7, gs.exp_count)
+        gs.exp_count += 1
+        # tolerance: 1e-3 (north star) would be loose; fp32 re-association gives ~1e-6
+        assert_close(head.weight_grad, fx[f"c{i}.G"], atol=1e-8, rtol=2e-5, name=f"G call {i}")
+        Pl = gs.Pl.cpu()
+        assert_close(Pl[:8, :8], fx[f"c{i}.Pl.corner"], atol=1e-8, rtol=2e-5, name="Pl corner")
+        assert_close(Pl[::16, ::16], fx[f"c{i}.Pl.sub"], atol=1e-8, rtol=2e-5, name="Pl sub")
+        assert_close(Pl.sum(1), fx[f"c{i}.Pl.rowsum"], atol=1e-7, rtol=2e-5, name="Pl rowsum")
+        assert abs(torch.linalg.norm(Pl).item() - float(fx[f"c{i}.Pl.fro"])) < 1e-5
+
+
+def test_gs_project_vs_oracle_and_modes(ops):
+    from mla_hip import GSPlugin, SharedHead
+    D, C, B = 512, 6, 16
+    head = SharedHead(D, C, seed=1)
+    for mode in ("as_published", "as_intended"):
+        gs = GSPlugin(dim=D, mode=mode)
+        Pl = torch.eye(D)
+        for i in range(3):
+            X = O.portable_normal(50 + i, (B, D), stream=1).abs()
+            G = O.portable_normal(50 + i, (C, D), stream=2, std=0.1)
+            head.weight_grad.copy_(G)
+            gs.before_update(head, X.cuda(), i, 5, gs.exp_count)
+            Pl, Gr = O.gs_before_update(Pl, X, G, i, 5, gs.exp_count, mode)
+            gs.exp_count += 1
+            assert_close(head.weight_grad, Gr, atol=1e-8, rtol=2e-5, name=f"{mode} G {i}")
+            assert_close(gs.Pl, Pl, atol=1e-8, rtol=2e-5, name=f"{mode} Pl {i}")
+        if mode == "as_published":
+            assert torch.equal(gs.Pl.cpu(), torch.eye(D))                      # Q1: never fires
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1027, 3078, 1 << 20])
+def test_sgd(ops, n):
+    p = O.portable_normal(n, (n,), stream=1)
+    g = O.portable_normal(n, (n,), stream=2)
+    pd, buf = p.cuda(), torch.zeros(n, device="cuda")
+    pr, br = p.clone(), None
+    for step, grad in enumerate([g, 0.5 * g, None, g]):                         # None = zeroed gradient (Q6)
+        ops.sgd_step(pd, None if grad is None else grad.cuda(), buf, 1e-3, 0.9, 1e-4, first=(step == 0))
+        pr, br = O.sgd_step(pr, grad, br, 1e-3)
+        assert_close(pd, pr, atol=1e-7, rtol=1e-6, name=f"sgd p step {step}")
+        assert_close(buf, br, atol=1e-7, rtol=1e-6, name=f"sgd buf step {step}")

@@ -1,0 +1,151 @@
+"""Whole-step parity: MLATrainer.train_step (HIP) vs the reference's golden outputs and vs the oracle.
+
+Tolerance (BASELINE.json north_star): logits, loss and the projected head gradient within 1e-3
+absolute in fp32.  We test tighter: 2e-4 absolute on features/logits/losses/head gradients.  Encoder
+gradients and updated encoder weights use the outlier-robust norm-wise check (tests/util.py).
+Pinned semantics: projection mode as named per case (Q1); zero_grad = torch>=2 set_to_none unless the
+case says "legacy" (Q6).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mla_oracle as O  # noqa: E402
+from util import assert_close, assert_close_robust  # noqa: E402
+
+TOL = 2e-4
+
+
+def build(seed, gs_mode, legacy):
+    from mla_hip import AVClassifier, MLATrainer
+
+    class Args:
+        fusion_method, dataset, gs_flag, modulation = "concat", "CREMAD", True, "Normal"
+
+    model = AVClassifier(Args(), seed=0)
+    pa, pv = O.make_resnet18_params("audio", seed), O.make_resnet18_params("visual", seed + 1)
+    hd = O.make_head_params(512, 6, seed + 2)
+    sd = {f"module.audio_net.{k}": v for k, v in pa.items()}                    # DataParallel-style keys (main.py:724)
+    sd.update({f"module.visual_net.{k}": v for k, v in pv.items()})
+    sd.update({f"module.fusion_module.fc_out.{k}": v for k, v in hd.items()})
+    model.load_state_dict(sd)
+    tr = MLATrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, gs_mode=gs_mode, legacy_zero_grad=legacy)
+    tr.keep_debug = True
+    st = O.MLAState(pa, pv, hd)
+    return model, tr, st
+
+
+def inputs(seed, s, B, spec_hw, T, img_hw):
+    spec = O.portable_normal(seed + 100 + s, (B,) + tuple(spec_hw), stream=1, mean=-5.081, std=4.4849)
+    image = O.portable_normal(seed + 100 + s, (B, 3, T) + tuple(img_hw), stream=2)
+    label = O.portable_labels(seed + 100 + s, B, 6)
+    return spec, image, label
+
+
+@pytest.mark.parametrize("tag", ["small_intended", "small_published", "small_legacy", "full_b2"])
+def test_step_vs_reference_golden(tag, golden_dir):
+    fx = np.load(os.path.join(golden_dir, f"mla_{tag}.npz"))
+    B, sh, sw, T, ih, iw, steps, seed, ldl = [int(v) for v in fx["meta"]]
+    gs_mode, legacy = str(fx["gs_mode"]), bool(int(fx["legacy"]))
+    model, tr, _ = build(seed, gs_mode, legacy)
+    for s in range(steps):
+        spec, image, label = inputs(seed, s, B, (sh, sw), T, (ih, iw))
+        losses = tr.train_step(spec.cuda(), image.cuda(), label.cuda(), s, ldl)
+        torch.cuda.synchronize()
+        for k in ("a", "v", "out_a", "out_v"):
+            assert_close(tr.last[k], fx[f"s{s}.{k}"], atol=TOL, name=f"{tag} s{s} {k}")
+        for k in ("loss", "loss_a", "loss_v"):
+            assert_close(losses[k].reshape(()), fx[f"s{s}.{k}"], atol=TOL, name=f"{tag} s{s} {k}")
+        assert_close(tr.last["head_grad_a_raw"], fx[f"s{s}.head_grad_a_raw"], atol=TOL, name="raw head grad a")
+        assert_close(tr.last["head_grad_v_raw"], fx[f"s{s}.head_grad_v_raw"], atol=TOL, name="raw head grad v")
+        # projected head gradient of the last (visual) phase is still in the head's grad buffer
+        assert_close(model.fusion_module.fc_out.weight_grad, fx[f"s{s}.head_grad_v"], atol=TOL, name="projected head grad v")
+        sd = model.state_dict()
+        assert_close(sd["fusion_module.fc_out.weight"], fx[f"s{s}.head.weight"], atol=TOL, name="head weight")
+        assert_close(sd["fusion_module.fc_out.bias"], fx[f"s{s}.head.bias"], atol=TOL, name="head bias")
+        for enc in ("audio_net", "visual_net"):
+            assert_close(sd[f"{enc}.bn1.running_mean"], fx[f"s{s}.{enc}.bn1.running_mean"], atol=1e-5, rtol=1e-5, name="running_mean")
+            assert_close(sd[f"{enc}.bn1.running_var"], fx[f"s{s}.{enc}.bn1.running_var"], atol=1e-5, rtol=1e-5, name="running_var")
+            assert_close_robust(sd[f"{enc}.conv1.weight"], fx[f"s{s}.{enc}.conv1.weight"], rel_l2=1e-4, elem_tol=1e-4, name=f"{enc} conv1.weight")
+            w = sd[f"{enc}.layer4.1.conv2.weight"]
+            assert_close(w.flatten()[:64], fx[f"s{s}.{enc}.layer4.1.conv2.weight.head"], atol=1e-6, name="layer4 weight slice")
+            assert abs(w.double().sum().item() - float(fx[f"s{s}.{enc}.layer4.1.conv2.weight.sum"])) < 1e-3
+        enc_g = {"audio": model.audio_net.grads_as_reference(), "visual": model.visual_net.grads_as_reference()}
+        for key in fx.files:
+            if key.startswith(f"s{s}.grad.") and key.endswith(".head"):
+                _, _, enc, *rest = key.split(".")
+                name = ".".join(rest[:-1])
+                g = enc_g[enc][name]
+                want_abs = float(fx[key[:-5] + ".abssum"])
+                got_abs = g.double().abs().sum().item()
+                assert abs(got_abs - want_abs) <= 5e-3 * want_abs + 1e-9, f"{key}: abssum {got_abs} vs {want_abs}"
+        # Pl digest (as_intended fires from the 2nd before_update call on)
+        Pl = tr.gs_plugin.Pl.cpu()
+        assert_close(Pl[:8, :8], fx[f"s{s}.Pl.corner"], atol=1e-6, rtol=1e-4, name="Pl corner")
+        assert_close(Pl[::16, ::16], fx[f"s{s}.Pl.sub"], atol=1e-6, rtol=1e-4, name="Pl sub")
+        assert abs(torch.trace(Pl).item() - float(fx[f"s{s}.Pl.trace"])) < 1e-4
+
+
+@pytest.mark.parametrize("B,spec_hw,T,img_hw", [(3, (96, 64), 3, (64, 64)), (8, (256, 128), 3, (112, 112))])
+def test_step_vs_oracle_all_grads(B, spec_hw, T, img_hw):
+    """Every encoder gradient tensor, every updated parameter, BN buffers: HIP vs oracle, 2 steps."""
+    seed = 31
+    model, tr, st = build(seed, "as_intended", False)
+    for s in range(2):
+        spec, image, label = inputs(seed, s, B, spec_hw, T, img_hw)
+        ref = O.mla_step(st, spec, image, label, s, 10)
+        losses = tr.train_step(spec.cuda(), image.cuda(), label.cuda(), s, 10)
+        torch.cuda.synchronize()
+        for k in ("a", "v", "out_a", "out_v"):
+            assert_close(tr.last[k], ref[k], atol=TOL, name=f"s{s} {k}")
+        for k in ("loss", "loss_a", "loss_v"):
+            assert_close(losses[k].reshape(()), ref[k], atol=TOL, name=f"s{s} {k}")
+        assert_close(model.fusion_module.fc_out.weight_grad, ref["head_grad_v"], atol=TOL, name="projected head grad")
+        for enc, net in (("audio", model.audio_net), ("visual", model.visual_net)):
+            got = net.grads_as_reference()
+            for k, want in ref["grads_" + enc].items():
+                assert_close_robust(got[k], want, rel_l2=5e-3, elem_tol=1e-3, frac=0.9, name=f"s{s} grad {enc}.{k}")
+            sd = net.state_dict()
+            params = st.audio if enc == "audio" else st.visual
+            for k, want in params.items():
+                if k.endswith("num_batches_tracked"):
+                    assert int(sd[k]) == int(want)
+                else:
+                    assert_close_robust(sd[k], want, rel_l2=1e-4, elem_tol=1e-4, name=f"s{s} state {enc}.{k}")
+        assert_close(tr.gs_plugin.Pl, st.Pl, atol=1e-6, rtol=1e-4, name="Pl")
+        assert tr.gs_plugin.exp_count == st.exp_count
+
+
+def test_adjoint_identities_full_size():
+    """Size-independent property at the CREMA-D layer shapes (B=64): <dY, conv(X,W)> = <dgrad(dY), X> =
+    <wgrad(X,dY), W>.  Exercises the three conv kernels at BASELINE.json's full sizes without a CPU oracle."""
+    from mla_hip import ops
+    torch.manual_seed(0)
+    cases = [(64, 256, 32, 64, 64, 3, 1, 1), (64, 256, 32, 64, 128, 3, 2, 1), (192, 14, 14, 256, 512, 3, 2, 1),
+             (192, 7, 7, 512, 512, 3, 1, 1), (64, 128, 16, 128, 256, 1, 2, 0)]
+    for (N, H, W, Cin, Cout, k, s, p) in cases:
+        x = torch.randn((N, H, W, Cin), device="cuda")
+        w = torch.randn((k, k, Cin, Cout), device="cuda") * 0.05
+        y, _ = ops.conv2d_fwd(x, w, s, p)
+        dy = torch.randn_like(y)
+        dx = ops.conv2d_dgrad(dy, w, x.shape, s, p, torch.empty(w.numel(), device="cuda"))
+        ws = torch.empty(ops.conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, k, k, s, p) // 4 + 4, device="cuda")
+        dw = ops.conv2d_wgrad(x, dy, torch.empty_like(w), s, p, ws)
+        a = (dy.double() * y.double()).sum().item()
+        b = (dx.double() * x.double()).sum().item()
+        c = (dw.double() * w.double()).sum().item()
+        scale = (dy.double().norm() * y.double().norm()).item()
+        assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+
+
+def test_loud_failure_without_gpu_library(monkeypatch):
+    """The product path has no fallback: a missing libmla_hip.so raises."""
+    from mla_hip import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmla_hip.so")
+    with pytest.raises(_lib.MLAHipError):
+        _lib.load()
