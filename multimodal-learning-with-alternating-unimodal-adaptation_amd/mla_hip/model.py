@@ -40,21 +40,21 @@ class SharedHead:
         gen.manual_seed(seed) if seed is not None else gen.seed()
         std = math.sqrt(2.0 / (in_features + out_features))           # xavier_normal_, utils/utils.py:107-109
         self.weight.copy_(torch.randn((out_features, in_features), generator=gen) * std)
-        self._ws: Dict[int, dict] = {}
+        self._ws: dict = {}
 
-    def _buffers(self, B: int) -> dict:
-        if B not in self._ws:
+    def _buffers(self, B: int, slot: str = "") -> dict:
+        if (B, slot) not in self._ws:
             f32 = dict(device=self.device, dtype=torch.float32)
-            self._ws[B] = {"logits": torch.empty((B, self.out_features), **f32), "loss": torch.empty(1, **f32),
+            self._ws[(B, slot)] = {"logits": torch.empty((B, self.out_features), **f32), "loss": torch.empty(1, **f32),
                            "dX": torch.empty((B, self.in_features), **f32),
                            "ws": torch.empty(ops.head_ws_elems(B, self.out_features), **f32)}
-        return self._ws[B]
+        return self._ws[(B, slot)]
 
-    def forward_backward(self, X: torch.Tensor, labels: torch.Tensor, inv_batch: Optional[float] = None):
+    def forward_backward(self, X: torch.Tensor, labels: torch.Tensor, inv_batch: Optional[float] = None, slot: str = ""):
         """logits, CE loss and all gradients (main.py:432-435).  Gradients land in
         self.weight_grad / self.bias_grad; returns (logits, loss[1], dX).  inv_batch = 1/global batch."""
         B = X.shape[0]
-        buf = self._buffers(B)
+        buf = self._buffers(B, slot)
         ops.head_ce_fwd_bwd(X, self.weight, self.bias, labels, buf["logits"], buf["loss"], self.weight_grad,
                             self.bias_grad, buf["dX"], buf["ws"], (1.0 / B) if inv_batch is None else inv_batch)
         return buf["logits"], buf["loss"], buf["dX"]

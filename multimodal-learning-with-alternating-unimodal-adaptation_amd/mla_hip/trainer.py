@@ -45,7 +45,7 @@ class MLATrainer:
     def _phase(self, name: str, enc, feat: torch.Tensor, pooled_px: int, label: torch.Tensor, inv_batch: float,
                batch_step: int, len_dataloader: int, pending: list):
         world = self.comm.world
-        logits, loss, dX = self.head.forward_backward(feat, label, inv_batch)               # :432-435
+        logits, loss, dX = self.head.forward_backward(feat, label, inv_batch, slot=name)               # :432-435
         self.last["out_" + name] = logits
         self.losses["loss_" + name].copy_(loss)
         enc.backward_from_pooled(dX, pooled_px)                                               # loss.backward()
