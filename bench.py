@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- samples/s of the MLA alternating-unimodal training step (main.py:419-476) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]; configs[2] for N>1): CREMA-D, --gs_flag, ResNet-18 audio+visual,
+per-GPU batch 64 of synthetic (1x1024x128 spectrogram + 3x3x224x224 frames), fp32, weak scaling.
+One "step" = joint encoder forward + 2 x {head fwd/CE/bwd, encoder backward, GS projection, SGD}.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with
+`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM convolution, HIP events over the timed region)
+and `cpu_baseline` (the CPU oracle = "port" of the reference path, timed on this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "multimodal-learning-with-alternating-unimodal-adaptation_amd"))
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+SPEC_HW, FRAMES, IMG_HW, N_CLASSES = (1024, 128), 3, (224, 224), 6
+
+
+class Args:
+    fusion_method, dataset, gs_flag, modulation = "concat", "CREMAD", True, "Normal"
+
+
+def usable_cores() -> int:
+    """CPU cores this process may really use: min(affinity, cgroup quota) -- the GPU box exposes far more
+    cores than its CPU share, and oversubscribing torch's thread pool stalls for minutes."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(batch: int = 8, max_steps: int = 5, budget_s: float = 25.0) -> dict:
+    """The CPU oracle (oracle/mla_oracle.py: the reference path restated on torch-CPU ATen kernels),
+    timed on this host: bounded sample = up to `max_steps` MLA steps at batch `batch` (about `budget_s`
+    seconds of CPU work) after one warm-up step."""
+    from oracle import mla_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: {cores} threads, batch {batch}", file=sys.stderr, flush=True)
+    st = O.MLAState(O.make_resnet18_params("audio", 1), O.make_resnet18_params("visual", 2), O.make_head_params(512, 6, 3))
+    g = torch.Generator().manual_seed(0)
+    spec = torch.randn((batch,) + SPEC_HW, generator=g) * 4.4849 - 5.081
+    image = torch.randn((batch, 3, FRAMES) + IMG_HW, generator=g)
+    label = torch.randint(0, N_CLASSES, (batch,), generator=g)
+    t_start = time.perf_counter()
+    O.mla_step(st, spec, image, label, 0, 100)
+    print(f"[bench] cpu_baseline warm-up step {time.perf_counter() - t_start:.2f} s", file=sys.stderr, flush=True)
+    ts = []
+    for s in range(max_steps):
+        t0 = time.perf_counter()
+        O.mla_step(st, spec, image, label, s + 1, 100)
+        ts.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline step {s}: {ts[-1]:.2f} s", file=sys.stderr, flush=True)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": round(batch / med, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(ts)} MLA steps at batch {batch} (same shapes, fp32, torch-CPU ATen), median, after 1 warm-up"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)        # RCCL over xGMI
+
+    from mla_hip import AVClassifier, Comm, MLATrainer, ops
+
+    model = AVClassifier(Args(), device=dev, seed=1234)        # weight_init distributions (utils/utils.py:106-114)
+    comm = Comm()
+    for buf in (model.audio_net.flat, model.visual_net.flat, model.fusion_module.fc_out.flat):
+        comm.broadcast_(buf, 0)                                 # replicas start identical (once, at init)
+    trainer = MLATrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, gs_mode="as_intended", comm=comm)
+
+    B = a.batch
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    spec = torch.randn((B,) + SPEC_HW, device=dev, generator=g) * 4.4849 - 5.081     # SURVEY 8d synthetic stats
+    image = torch.randn((B, 3, FRAMES) + IMG_HW, device=dev, generator=g)
+    label = torch.randint(0, N_CLASSES, (B,), device=dev, generator=g)
+    len_dl = 105                                                # CREMA-D: 6698 train clips / 64
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(a.warmup):
+        trainer.train_step(spec, image, label, s % len_dl, len_dl)
+    sync()
+    if rank == 0:
+        print(f"[bench] warm-up done ({a.warmup} steps); timing {a.steps} steps", file=sys.stderr, flush=True)
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        trainer.train_step(spec, image, label, (a.warmup + s) % len_dl, len_dl)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    if rank == 0:
+        print(f"[bench] timed region {dt:.3f} s", file=sys.stderr, flush=True)
+    loss = float(trainer.losses["loss"].item())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert loss == loss, "loss is NaN"
+
+    if rank == 0:
+        summ = timer.summary()
+        ig = {"ms": 0.0, "work": 0.0, "launches": 0}
+        for k in ("conv_fwd", "conv_dgrad"):                    # both are igemm_kernel launches
+            for f in ig:
+                ig[f] += summ.get(k, {}).get(f, 0)
+        achieved = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        per_kind = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
+                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+        out = {
+            "metric": "samples/sec per MLA alternating step, CREMA-D A+V bs=64",
+            "value": round(B * world * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CREMA-D MLA step (--gs_flag, --lorb base ResNet18 audio+visual, GS projection as_intended), "
+                                   "per-GPU batch %d: spec 1x1024x128 + frames 3x3x224x224, 6 classes" % B,
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(ig["ms"] / max(ig["launches"], 1), 4),
+                         "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2)},
+            "kernels": per_kind,
+            "final_loss": round(loss, 5),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

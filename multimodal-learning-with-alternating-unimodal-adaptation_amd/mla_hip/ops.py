@@ -18,6 +18,38 @@ BN_EPS = 1e-5        # nn.BatchNorm2d default (models/backbone.py:22)
 BN_MOMENTUM = 0.1
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around kernel launches (bench.py roofline).  Events are recorded on
+    the stream the kernels are launched on (torch's current stream), so elapsed_time is the launch's
+    device duration.  Off (None) in normal operation: zero overhead."""
+
+    def __init__(self):
+        self.records = []          # (kind, algorithmic work, start event, end event)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, kind: str, work: float, start) -> None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((kind, work, start, e))
+
+    def summary(self) -> dict:
+        """kind -> {'launches', 'ms', 'work'} (call after torch.cuda.synchronize())."""
+        out: dict = {}
+        for kind, work, s, e in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += work
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
 def cur_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -74,8 +106,11 @@ def conv2d_fwd(x: torch.Tensor, w_hwio: torch.Tensor, stride: int, pad: int, y: 
         y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout), device=x.device,
                         dtype=torch.float32)
     tiles = ctypes.c_int(0)
+    t0 = TIMER.begin() if TIMER is not None else None
     check(_lib.load().mla_conv2d_fwd(_p(x), _p(w_hwio), _p(y), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                      _p(bn_partial), ctypes.addressof(tiles), stream or cur_stream()), "mla_conv2d_fwd")
+    if t0 is not None:
+        TIMER.end("conv_fwd", 2.0 * y.numel() * KH * KW * Cin, t0)
     return y, tiles.value
 
 
@@ -88,8 +123,11 @@ def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_shape, stride: int, p
         dx = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
     if wt_ws.numel() < w_hwio.numel():
         raise MLAHipError("conv2d_dgrad: wt_ws too small")
+    t0 = TIMER.begin() if TIMER is not None else None
     check(_lib.load().mla_conv2d_dgrad(_p(dy), _p(w_hwio), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                        _p(residual), _p(relu_src), _p(wt_ws), stream or cur_stream()), "mla_conv2d_dgrad")
+    if t0 is not None:
+        TIMER.end("conv_dgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
     return dx
 
 
@@ -101,8 +139,11 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_hwio: torch.Tensor, strid
                  stream: Optional[int] = None) -> torch.Tensor:
     N, H, W, Cin = x.shape
     KH, KW, _, Cout = dw_hwio.shape
+    t0 = TIMER.begin() if TIMER is not None else None
     check(_lib.load().mla_conv2d_wgrad(_p(x), _p(dy), _p(dw_hwio), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                        _p(ws), ws.numel() * ws.element_size(), stream or cur_stream()), "mla_conv2d_wgrad")
+    if t0 is not None:
+        TIMER.end("conv_wgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
     return dw_hwio
 
 
