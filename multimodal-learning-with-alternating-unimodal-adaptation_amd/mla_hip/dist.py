@@ -24,16 +24,19 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, group=None, bucket_bytes: int = 16 << 20):
+    def __init__(self, group=None, bucket_bytes: int = 16 << 20, force: bool = False):
+        """force=True issues every collective even with a single rank (used to rehearse the RCCL path on
+        a one-GPU box); results are unchanged because SUM over one rank is the identity."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.active = (self.world > 1) or (force and dist.is_initialized())
 
     # ---- encoder gradients ------------------------------------------------------------------
     def allreduce_flat_async(self, flat: torch.Tensor) -> List:
         """all-reduce(SUM) `flat` in place in buckets; returns the work handles (empty if world == 1)."""
-        if self.world == 1:
+        if not self.active:
             return []
         works = []
         for o in range(0, flat.numel(), self.bucket_elems):
@@ -49,7 +52,7 @@ class Comm:
     def exchange_head(self, head_grad_flat: torch.Tensor, colsum: torch.Tensor, loss: torch.Tensor,
                       scratch: Optional[torch.Tensor] = None) -> None:
         """In-place SUM over ranks of (dW|db), the feature column sum and the loss: one message."""
-        if self.world == 1:
+        if not self.active:
             return
         n0, n1 = head_grad_flat.numel(), colsum.numel()
         n = n0 + n1 + 1
@@ -63,5 +66,5 @@ class Comm:
         loss.reshape(1).copy_(msg[n0 + n1:])
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> None:
-        if self.world > 1:
+        if self.active:
             dist.broadcast(t, src=src, group=self.group)

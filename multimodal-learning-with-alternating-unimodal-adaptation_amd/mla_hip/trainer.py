@@ -44,7 +44,6 @@ class MLATrainer:
 
     def _phase(self, name: str, enc, feat: torch.Tensor, pooled_px: int, label: torch.Tensor, inv_batch: float,
                batch_step: int, len_dataloader: int, pending: list):
-        world = self.comm.world
         logits, loss, dX = self.head.forward_backward(feat, label, inv_batch, slot=name)               # :432-435
         self.last["out_" + name] = logits
         self.losses["loss_" + name].copy_(loss)
@@ -52,7 +51,7 @@ class MLATrainer:
         works = self.comm.allreduce_flat_async(enc.grad)                                     # overlaps what follows
         fires = self.gs_plugin.mode == "as_intended" and self.gs_plugin.exp_count != 0
         r_mean = None
-        if world > 1:
+        if self.comm.active:
             ops.colsum(feat, self._colsum, inv_batch)
             self.comm.exchange_head(self.head.grad, self._colsum, self.losses["loss_" + name], self._msg)
             r_mean = self._colsum
@@ -85,13 +84,13 @@ class MLATrainer:
         # phase does not read audio parameters, so enqueueing it first changes no result.
         self._phase("a", m.audio_net, a, m._pa, label, inv_batch, batch_step, len_dataloader, pending)
         opt.mark_ready("audio")
-        if self.comm.world == 1:
+        if not self.comm.active:
             opt.step_group("audio")
         opt_legacy_audio = opt.legacy_zero_grad
         # ---- visual phase
         self._phase("v", m.visual_net, v, m._pv, label, inv_batch, batch_step, len_dataloader, pending)
         opt.mark_ready("visual")
-        if self.comm.world > 1:
+        if self.comm.active:
             self.comm.wait(pending[0][1])
             opt.step_group("audio")
             self.comm.wait(pending[1][1])

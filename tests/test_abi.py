@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mla_hip.h declares (no compute calls),
+the ctypes prototype table mirrors the header, and host-side logic that needs no GPU."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "mla_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    decls = re.findall(r"\b(mla_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S)
+    return {name: [a.strip() for a in args.split(",")] if args.strip() != "void" else [] for name, args in decls}
+
+
+def test_library_exports_every_declared_symbol():
+    from mla_hip import _lib
+    lib = _lib.load()                     # built by __graft_entry__.build(); raises loudly if missing
+    fns = header_functions()
+    assert len(fns) >= 26
+    for name in fns:
+        assert hasattr(lib, name), f"libmla_hip.so does not export {name}"
+    assert lib.mla_abi_version() == 1
+    assert lib.mla_last_error() is not None
+
+
+def test_ctypes_table_mirrors_header():
+    from mla_hip import _lib
+    fns = header_functions()
+    assert set(fns) == set(_lib.PROTOTYPES), set(fns) ^ set(_lib.PROTOTYPES)
+    for name, args in fns.items():
+        assert len(args) == len(_lib.PROTOTYPES[name][1]), f"{name}: header has {len(args)} args"
+
+
+def test_no_torch_types_in_abi():
+    txt = open(os.path.join(ROOT, "include", "mla_hip.h")).read()
+    assert "torch" not in txt.lower().replace("pytorch", "") or "at::" not in txt
+    assert "at::Tensor" not in txt and "#include <torch" not in txt
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, "multimodal-learning-with-alternating-unimodal-adaptation_amd")
+    for dp, _dn, fn in os.walk(pkg):
+        for f in fn:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from mla_hip import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmla_hip.so")
+    with pytest.raises(_lib.MLAHipError):
+        _lib.load()
+
+
+def test_encoder_layout_and_state_dict_roundtrip_cpu():
+    """Flat-buffer layout + reference key names / OIHW conversion (host logic only, CPU tensors)."""
+    from mla_hip.encoder import ResNet18Encoder, conv_specs, bn_name_for_conv
+    from oracle import mla_oracle as O
+    assert conv_specs("audio") == O.resnet18_conv_specs("audio")
+    assert conv_specs("visual") == O.resnet18_conv_specs("visual")
+    with pytest.raises(NotImplementedError):
+        conv_specs("text")                                  # backbone.py:84-85
+    assert bn_name_for_conv("layer2.0.downsample.0") == "layer2.0.downsample.1"
+    for mod, n_params in (("audio", 11170240), ("visual", 11176512)):     # SURVEY section 6 [probed]
+        enc = ResNet18Encoder(mod, device="cpu", seed=0)
+        assert enc.numel == n_params
+        ref = O.make_resnet18_params(mod, 5)
+        enc.load_state_dict(ref)
+        sd = enc.state_dict()
+        assert list(sd.keys()) == list(ref.keys())          # reference module order
+        for k in ref:
+            assert torch.equal(sd[k].cpu(), ref[k]), k
+        # every segment of the flat buffer is 16-byte aligned (float4 SGD / all-reduce buckets)
+        assert all(o % 4 == 0 for o, _ in enc.layout.values())
+
+
+def test_avclassifier_error_behaviour_cpu():
+    from mla_hip import AVClassifier
+
+    class A:
+        fusion_method, dataset, gs_flag, modulation = "concat", "CREMA-D", True, "Normal"
+    with pytest.raises(NotImplementedError, match="Incorrect dataset name"):       # basic_model.py:26 (Q11 spelling)
+        AVClassifier(A(), device="cpu")
+    A.dataset, A.fusion_method = "CREMAD", "film"
+    with pytest.raises(NotImplementedError, match="Incorrect fusion method"):      # basic_model.py:40
+        AVClassifier(A(), device="cpu")
+    A.fusion_method = "concat"
+    m = AVClassifier(A(), device="cpu", seed=0)
+    sd = m.state_dict("module.")
+    assert "module.audio_net.conv1.weight" in sd and "module.fusion_module.fc_out.weight" in sd
+    assert sd["module.visual_net.conv1.weight"].shape == (64, 3, 7, 7)
+    assert m.module.fusion_module.fc_out.weight.shape == (6, 512)
+    m.load_state_dict(sd)
+
+
+def test_gs_alpha_and_sgd_state_machine_cpu():
+    from mla_hip import FusedSGD, GSPlugin
+    assert abs(GSPlugin.alpha(0, 10) - 0.1) < 1e-12 and abs(GSPlugin.alpha(5, 10) - 0.1 ** 1.5) < 1e-12
+
+    class G:
+        def __init__(self):
+            self.flat, self.grad = torch.zeros(8), torch.zeros(8)
+    for legacy, want in ((False, "none"), (True, "zero")):
+        opt = FusedSGD({"audio": G(), "visual": G(), "head": G()}, legacy_zero_grad=legacy)
+        opt.mark_ready("audio")
+        opt.zero_grad()
+        assert opt.grad_state["audio"] == want and opt.grad_state["visual"] == "none"     # Q6
+        opt.drop_grads()
+        assert set(opt.grad_state.values()) == {"none"}

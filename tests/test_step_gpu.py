@@ -176,3 +176,34 @@ def test_loud_failure_without_gpu_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmla_hip.so")
     with pytest.raises(_lib.MLAHipError):
         _lib.load()
+
+
+def test_rccl_path_single_rank_matches_local():
+    """Rehearse the RCCL code path (nccl backend = RCCL) on one GPU: a single-rank process group with
+    Comm(force=True) issues the bucketed async encoder-gradient all-reduce and the packed head exchange on
+    RCCL's stream; the step must equal the non-distributed step exactly (SUM over one rank = identity)."""
+    import socket
+    import torch.distributed as dist
+    from mla_hip import Comm, MLATrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        seed, B = 41, 4
+        model_d, _, _ = build(seed, "as_intended", False)
+        tr_d = MLATrainer(model_d, comm=Comm(force=True, bucket_bytes=8 << 20))
+        model_l, tr_l, _ = build(seed, "as_intended", False)
+        assert tr_d.comm.active and not tr_l.comm.active
+        for step in range(3):
+            spec, image, label = inputs(seed, step, B, (128, 64), 2, (64, 64))
+            ld = tr_d.train_step(spec.cuda(), image.cuda(), label.cuda(), step, 10)
+            ll = tr_l.train_step(spec.cuda(), image.cuda(), label.cuda(), step, 10)
+            torch.cuda.synchronize()
+            for k in ("loss", "loss_a", "loss_v"):
+                assert torch.equal(ld[k].cpu(), ll[k].cpu()), k
+        assert torch.equal(model_d.audio_net.flat.cpu(), model_l.audio_net.flat.cpu())
+        assert torch.equal(model_d.visual_net.flat.cpu(), model_l.visual_net.flat.cpu())
+        assert torch.equal(model_d.fusion_module.fc_out.flat.cpu(), model_l.fusion_module.fc_out.flat.cpu())
+        assert torch.equal(tr_d.gs_plugin.Pl.cpu(), tr_l.gs_plugin.Pl.cpu())
+    finally:
+        dist.destroy_process_group()
