@@ -15,8 +15,9 @@
 // (channels x cout) staged through LDS with register prefetch of the next K step; every wave owns a
 // (BM/WM)x(BN/WN) sub-tile as 32x32 MFMA tiles.  fp32 MFMA moves 512 B of LDS per 64-cycle
 // instruction, so the kernel is MFMA-issue bound; >= 2 workgroups per CU hide each other's barriers.
-// The tap table is read with scalar loads and the gathers are branch-free, so nothing in the loop
-// waits on vmcnt except the LDS store of the prefetched tile.
+// Gathers are raw buffer loads (hardware range check = zero padding), row offsets and tap-validity masks
+// are per-thread constants and the tap table is read with scalar loads, so a K step spends ~35 VALU
+// instructions on addressing and nothing in the loop waits on vmcnt except the LDS store of the prefetch.
 #include "common.h"
 
 #define MAX_TAPS 49
@@ -33,12 +34,27 @@ struct IGemmGeom {
   int T;                   // number of taps
   int M;                   // N*OH*OW
   int K;                   // scalar-gather mode: T*C (un-padded flattened K)
+  unsigned x_bytes, w_bytes, y_bytes;   // byte sizes of the gathered tensor, the weights and the second operand (wgrad: dY)
   int tap[MAX_TAPS];       // (dy & 0xff) | (dx & 0xff) << 8 | wt << 16   (int32: read with s_load_dword)
 };
 
-// Zero page for padding / out-of-range rows: the gathers stay branch-free AND select-free (a select on
-// the loaded value would make the compiler wait for the prefetch before the MFMA block).
-__device__ float mla_zero_page[1024];
+// Gathers use raw buffer loads: the hardware range check of the buffer descriptor returns 0 for any
+// offset >= num_records, so padding / out-of-range rows are "loaded" as zeros by pointing them at
+// OOB_OFF -- no zero page, no pointer select, no branch, and no select on the loaded value (which would
+// make the compiler wait for the prefetch before the MFMA block).  Offsets are 32-bit: tensors < 4 GiB.
+#define OOB_OFF 0xFFFFFFFFu
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned voff, unsigned soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
 
 static inline int pack_tap(int dy, int dx, int wt) { return (dy & 0xff) | ((dx & 0xff) << 8) | (wt << 16); }
 __device__ __forceinline__ int tap_dy(int t) { return (int)(signed char)(t & 0xff); }
@@ -130,27 +146,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
   float asc[SCALAR_A ? BM / 8 : 1];
   f32x4 breg[BPASS];
 
-  // Branch-free gathers: an out-of-image (padding) or out-of-range row reads pixel 0 of the tensor
-  // (always valid memory) and is zeroed by a select, so all loads of a K step issue back to back.
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), wr = make_rsrc(Wt, g.w_bytes);
+  // Per-thread gather state, computed once: byte offset of each of this thread's rows at tap (0,0) and a
+  // bitmask of the taps that fall inside the image.  Per K step a row then costs 3 VALU ops + 1 buffer load.
+  unsigned rowoff[SCALAR_A ? 1 : APASS], tmask[SCALAR_A ? 1 : APASS], boff[BPASS];
+  if constexpr (!SCALAR_A) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const int4 info = rowinfo[p * 32 + (tid >> 3)];
+      rowoff[p] = ((unsigned)(info.x + info.y * gW + info.z) * (unsigned)gC + (tid & 7) * 4) * 4u;
+      unsigned m = 0;
+      for (int t = 0; t < g.T; ++t) {
+        const int tp = g.tap[t];
+        const int iy = info.y + tap_dy(tp), ix = info.z + tap_dx(tp);
+        m |= ((unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW) ? (1u << t) : 0u;   // invalid rows: -100000
+      }
+      tmask[p] = m;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < BPASS; ++p) boff[p] = ((p * BROWS + tid / (BN / 4)) * gCO + (tid % (BN / 4)) * 4) * 4u;
+
   auto load_tiles = [&](int it) {
     if constexpr (!SCALAR_A) {
       const int t = it / cpt, c0 = (it - t * cpt) * BK;
       const int tp = g.tap[t];
-      const int dy = tap_dy(tp), dx = tap_dx(tp);
+      const unsigned toff = (unsigned)(((tap_dy(tp) * gW + tap_dx(tp)) * gC + c0) * 4);   // wave-uniform (SGPR)
 #pragma unroll
-      for (int p = 0; p < APASS; ++p) {
-        const int4 info = rowinfo[p * 32 + (tid >> 3)];
-        const int iy = info.y + dy, ix = info.z + dx;
-        const bool ok = (unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW;   // invalid rows carry -100000
-        const float* src = ok ? X + (size_t)(info.x + iy * gW + ix) * gC : mla_zero_page;
-        areg[p] = *reinterpret_cast<const f32x4*>(src + c0 + (tid & 7) * 4);
-      }
-      const float* wsrc = Wt + ((size_t)tap_wt(tp) * gC + c0) * gCO + tn * BN;
+      for (int p = 0; p < APASS; ++p)
+        areg[p] = buf_load4(xr, ((tmask[p] >> t) & 1u) ? rowoff[p] + toff : OOB_OFF, 0);
+      const unsigned wsoff = (unsigned)(((tap_wt(tp) * gC + c0) * gCO + tn * BN) * 4);    // wave-uniform
 #pragma unroll
-      for (int p = 0; p < BPASS; ++p) {
-        const int row = p * BROWS + tid / (BN / 4), c4 = tid % (BN / 4);
-        breg[p] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)row * gCO + c4 * 4);
-      }
+      for (int p = 0; p < BPASS; ++p) breg[p] = buf_load4(wr, boff[p], wsoff);
     } else {
       const int kg = it * BK + (tid & 31);
       const bool kok = kg < g.K;
@@ -162,15 +189,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
         const int4 info = rowinfo[p * 8 + (tid >> 5)];
         const int iy = info.y + dy, ix = info.z + dx;
         const bool ok = kok && (unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW;
-        const float* src = ok ? X + (size_t)(info.x + iy * gW + ix) * gC + ci : mla_zero_page;
-        asc[p] = *src;
+        asc[p] = buf_load1(xr, ok ? ((unsigned)(info.x + iy * gW + ix) * (unsigned)gC + ci) * 4u : OOB_OFF, 0);
       }
 #pragma unroll
       for (int p = 0; p < BPASS; ++p) {
-        const int row = p * BROWS + tid / (BN / 4), c4 = tid % (BN / 4);
-        const int kr = it * BK + row;
-        const float* src = kr < g.K ? Wt + (size_t)kr * gCO + tn * BN : mla_zero_page;
-        breg[p] = *reinterpret_cast<const f32x4*>(src + c4 * 4);
+        const int kr = it * BK + p * BROWS + tid / (BN / 4);
+        breg[p] = buf_load4(wr, kr < g.K ? (unsigned)(kr * gCO + tn * BN + (tid % (BN / 4)) * 4) * 4u : OOB_OFF, 0);
       }
     }
   };
@@ -190,13 +214,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
     }
   };
 
+  // Single LDS buffer + register prefetch, two barriers per K step.  Measured alternatives (a.l2/a.l3/a.l4
+  // shapes, same run): double-buffered LDS with one barrier per step -2 % (70 KB LDS -> 2 instead of 3
+  // resident workgroups); staggering co-resident workgroups +-0 %.  Timing-only ablations put the ceiling of
+  // this structure (LDS reads + MFMA only) at 147 TF, global loads cost ~5 %, LDS stores + 2nd barrier ~5 %;
+  // what recovers them is more resident workgroups per CU, hence the 64x64 tile for small / ragged problems.
+  const float* As_w = As + wm * (BM / WM) * LDA;
+  const float* Bs_w = Bs + wn * (BN / WN);
   if (nIter > 0) {  // nIter == 0: a dgrad parity class no tap reaches (1x1 stride 2): epilogue only
     load_tiles(0);
     store_tiles();
   }
   __syncthreads();
-  const float* As_w = As + wm * (BM / WM) * LDA;
-  const float* Bs_w = Bs + wn * (BN / WN);
   for (int it = 0; it < nIter; ++it) {
     const bool more = it + 1 < nIter;
     if (more) load_tiles(it + 1);
@@ -313,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
   constexpr int YROWS = 256 / (BJ / 4), YPASS = BK / YROWS;
   __shared__ __attribute__((aligned(16))) float Xs[BK * BI];
   __shared__ __attribute__((aligned(16))) float Ys[BK * BJ];
-  __shared__ int2 rowinfo[WG_CHUNK];  // {n*H*W + (oy*sy)*W + ox*sx (tap-free pixel index) or INT_MIN, (oy*sy)<<16 | (ox*sx)&0xffff}
+  __shared__ int2 rowinfo[WG_CHUNK];  // vector mode: {byte offset of the gathered X row for THIS block's tap or OOB_OFF, -};
+                                      // scalar mode: {n*H*W or -1, (oy*sy)<<16 | (ox*sx)&0xffff}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
@@ -350,19 +380,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
     dx = tap_dx(g.tap[t]);
   }
   const int i = lane & 31, h = lane >> 5;
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), yr = make_rsrc(dY, g.y_bytes);
 
   for (int c_begin = m_begin; c_begin < m_end; c_begin += WG_CHUNK) {
     const int c_end = min(m_end, c_begin + WG_CHUNK);
     __syncthreads();  // previous sub-chunk's readers are done with rowinfo / Xs / Ys
     for (int r = tid; r < WG_CHUNK; r += 256) {
       const int m = c_begin + r;
-      int2 info = make_int2(-1, (int)0x80008000);   // coordinates -32768: never in range
+      int2 info = make_int2(SCALAR_A ? -1 : (int)OOB_OFF, (int)0x80008000);   // coordinates -32768: never in range
       if (m < c_end) {
         const int ohw = g.OH * g.OW;
         const int n = m / ohw, rem = m - n * ohw;
         const int oy = rem / g.OW, ox = rem - oy * g.OW;
-        info.x = n * gH * gW;
-        info.y = ((oy * g.sy) << 16) | ((ox * g.sx) & 0xffff);
+        if constexpr (SCALAR_A) {
+          info.x = n * gH * gW;
+          info.y = ((oy * g.sy) << 16) | ((ox * g.sx) & 0xffff);
+        } else {
+          const int iy = oy * g.sy + dy, ix = ox * g.sx + dx;
+          if ((unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW)
+            info.x = (int)(((unsigned)(n * gH * gW + iy * gW + ix) * (unsigned)gC + ti * BI) * 4u);
+        }
       }
       rowinfo[r] = info;
     }
@@ -372,11 +409,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
       if constexpr (!SCALAR_A) {
 #pragma unroll
         for (int p = 0; p < XPASS; ++p) {
-          const int2 info = rowinfo[p0 + p * XROWS + tid / (BI / 4)];
-          const int iy = (info.y >> 16) + dy, ix = (int)(short)(info.y & 0xffff) + dx;
-          const bool ok = (unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW;
-          const float* src = ok ? X + (size_t)(info.x + iy * gW + ix) * gC + ti * BI : mla_zero_page;
-          xreg[p] = *reinterpret_cast<const f32x4*>(src + (tid % (BI / 4)) * 4);
+          const unsigned ro = (unsigned)rowinfo[p0 + p * XROWS + tid / (BI / 4)].x;
+          xreg[p] = buf_load4(xr, ro == OOB_OFF ? OOB_OFF : ro + (tid % (BI / 4)) * 16u, 0);   // no wrap past OOB_OFF
         }
       } else {
 #pragma unroll
@@ -384,15 +418,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
           const int2 info = rowinfo[p0 + p * (256 / BI) + tid / BI];
           const int iy = (info.y >> 16) + dy, ix = (int)(short)(info.y & 0xffff) + dx;
           const bool ok = kok && (unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW;
-          const float* src = ok ? X + (size_t)(info.x + iy * gW + ix) * gC + ci_s : mla_zero_page;
-          xsc[p] = *src;
+          xsc[p] = buf_load1(xr, ok ? ((unsigned)(info.x + iy * gW + ix) * (unsigned)gC + ci_s) * 4u : OOB_OFF, 0);
         }
       }
 #pragma unroll
       for (int p = 0; p < YPASS; ++p) {
         const int m = c_begin + p0 + p * YROWS + tid / (BJ / 4);
-        const float* src = m < c_end ? dY + (size_t)m * gCO + tj * BJ : mla_zero_page;
-        yreg[p] = *reinterpret_cast<const f32x4*>(src + (tid % (BJ / 4)) * 4);
+        yreg[p] = buf_load4(yr, m < c_end ? ((unsigned)m * (unsigned)gCO + tj * BJ + (tid % (BJ / 4)) * 4) * 4u : OOB_OFF, 0);
       }
     };
     auto store_tiles = [&]() {
@@ -491,6 +523,7 @@ static int check_conv(const char* who, int N, int H, int W, int Cin, int Cout, i
   MLA_REQUIRE(Cin % 64 == 0 || Cin <= 4, "%s: Cin=%d must be a multiple of 64 or <= 4 (stem)", who, Cin);
   MLA_REQUIRE(pad >= 0 && pad < 64 && H < 32768 && W < 32768, "%s: pad/size out of range", who);
   MLA_REQUIRE((long)N * H * W < (1L << 31) / 4, "%s: too many pixels for 32-bit pixel indices", who);
+  MLA_REQUIRE((long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 < 0xFFFFFFF0L, "%s: tensors must be < 4 GiB (32-bit buffer offsets)", who);
   return MLA_OK;
 }
 
@@ -502,7 +535,9 @@ static int cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : 64; }
 
 static int pick_cfg(const long* Ms, const int* weights, int n, int CO, bool scalar) {
   if (scalar) return CFG_256x64;
-  const double eff[3] = {1.0, 1.0, 0.80};
+  // measured on the ResNet-18 layer shapes (scripts/bench_conv.py): the 64x64 tile reaches 0.97 of the big
+  // tiles' per-flop rate, and any tile loses ~10 % when fewer than two workgroups are resident per CU.
+  const double eff[3] = {1.0, 1.0, 0.97};
   int best = -1;
   double best_cost = 0;
   for (int cfg = 0; cfg < 3; ++cfg) {
@@ -517,7 +552,7 @@ static int pick_cfg(const long* Ms, const int* weights, int n, int CO, bool scal
     if (blocks == 0) continue;
     const double avg_w = wblocks / blocks;                        // average taps per block
     const double rounds = (double)((long)((blocks + 255) / 256));
-    const double cost = rounds * avg_w * cfg_bm(cfg) * cfg_bn(cfg) / eff[cfg];
+    const double cost = rounds * avg_w * cfg_bm(cfg) * cfg_bn(cfg) / (eff[cfg] * (blocks < 512 ? 0.9 : 1.0));
     (void)wsum;
     if (best < 0 || cost < best_cost) { best = cfg; best_cost = cost; }
   }
@@ -564,6 +599,8 @@ extern "C" int mla_conv2d_fwd(const float* x, const float* w, float* y, int N, i
   g.T = KH * KW; g.M = N * g.OH * g.OW; g.K = g.T * Cin;
   for (int kh = 0; kh < KH; ++kh)
     for (int kw = 0; kw < KW; ++kw) g.tap[kh * KW + kw] = pack_tap(kh - pad, kw - pad, kh * KW + kw);
+  g.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
+  g.w_bytes = (unsigned)((size_t)g.T * Cin * Cout * 4);
   const int cfg = fwd_cfg(g.M, Cin, Cout);
   if (bn_tiles) *bn_tiles = cdiv(g.M, cfg_bm(cfg));
   return launch_igemm(x, w, y, nullptr, nullptr, bn_partial, g, Cin % 64 != 0, cfg, (hipStream_t)stream);
@@ -601,6 +638,8 @@ extern "C" int mla_conv2d_dgrad(const float* dy, const float* w, float* dx, int 
       // T == 0 (1x1 stride-2, odd parity): no tap reaches this class; its blocks still run so the
       // epilogue writes dx = residual (or 0) and applies the relu mask there.
       g.T = T; g.K = T * Cout;
+      g.x_bytes = (unsigned)((size_t)N * OH * OW * Cout * 4);
+      g.w_bytes = (unsigned)((size_t)KH * KW * Cin * Cout * 4);
       if (g.M <= 0) continue;
       const long Mc = g.M;
       const int wt = T > 0 ? T : 1;
@@ -643,6 +682,8 @@ extern "C" int mla_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
   g.sy = g.sx = stride; g.T = KH * KW; g.M = N * g.OH * g.OW; g.K = g.T * Cin;
   for (int kh = 0; kh < KH; ++kh)
     for (int kw = 0; kw < KW; ++kw) g.tap[kh * KW + kw] = pack_tap(kh - pad, kw - pad, kh * KW + kw);
+  g.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
+  g.y_bytes = (unsigned)((size_t)g.M * Cout * 4);
   int span, splits;
   wgrad_plan(g.M, Cin, Cout, g.T, &span, &splits);
   const size_t need = (size_t)splits * g.T * Cin * Cout * sizeof(float);
