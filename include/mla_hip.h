@@ -112,6 +112,50 @@ int mla_colsum(const float* X, float* r, int B, int D, float scale, void* stream
 size_t mla_gs_ws_elems(int D, int C);
 int mla_gs_project(float* Pl, const float* r, float* G, int D, int C, float alpha, float* ws, void* stream);
 
+/* ---- transformer encoders (M3AE, models/m3ae.py; CAV-MAE, models/cav_mae.py) ------------------- */
+/* nn.Linear on the gather-GEMM: y[g][y_off+r][:] = x[g][x_off+r][:] . w_kn (+ bias) (+ residual);
+ * rows are `groups` x `rows` tokens taken at an offset inside groups of *_group_rows tokens (no copies for
+ * "tokens 1..256 of each 257-token sequence").  w_kn is [K][N] = nn.Linear.weight^T.  y_gelu (nullable)
+ * additionally receives gelu(y) (erf form, F.gelu, m3ae.py:77).  K, N multiples of 64. */
+int mla_linear_fwd(const float* x, const float* w_kn, const float* bias, const float* residual, float* y,
+                   float* y_gelu, int groups, int rows, int x_group_rows, int x_off, int y_group_rows, int y_off,
+                   int K, int N, void* stream);
+/* dx = dy . w_kn^T (+ residual) (* gelu'(gelu_src)).  wt_ws: K*N floats. */
+int mla_linear_dgrad(const float* dy, const float* w_kn, float* dx, const float* residual, const float* gelu_src,
+                     float* wt_ws, int groups, int rows, int dy_group_rows, int dy_off, int dx_group_rows, int dx_off,
+                     int K, int N, void* stream);
+/* dw_kn[K][N] = sum_rows x^T dy (dy dense [groups*rows][N]); deterministic split-K like mla_conv2d_wgrad. */
+size_t mla_linear_wgrad_ws_bytes(int M, int K, int N);
+int mla_linear_wgrad(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows, int x_off,
+                     int K, int N, void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum_rows x[r][c]  (bias gradients).  ws: mla_colreduce_ws_elems(M, C) floats; C % 64 == 0. */
+size_t mla_colreduce_ws_elems(int M, int C);
+int mla_colsum_rows(const float* x, float* out, float* ws, int M, int C, void* stream);
+/* nn.LayerNorm (m3ae.py:138,142,176) over rows of D (512/768/1024); saves mean and rstd per row. */
+int mla_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                      int M, int D, float eps, void* stream);
+/* dx = LN'(dy) (+ add), dw = sum dy*xhat, db = sum dy.  dx may alias dy or add.  ws: mla_colreduce_ws_elems. */
+int mla_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                      const float* add, float* dx, float* dw, float* db, float* ws, int M, int D, void* stream);
+/* Strided batched GEMM for attention (m3ae.py:109, 121): C[z] = alpha * A[z] . B[z], z = (batch, head);
+ * strides in elements: a = {batch, head, row i, k}, b = {batch, head, k, col j}, c = {batch, head, i, j}. */
+int mla_bgemm(const float* A, const float* B, float* C, int batches, int heads, int M, int N, int K,
+              const long* a_strides, const long* b_strides, const long* c_strides, float alpha, void* stream);
+/* In-place softmax over the last axis of S (B,H,n,n); pad_mask (B,n) float, > 0 -> score := -1e7 (m3ae.py:111-118). */
+int mla_softmax_fwd(float* S, const float* pad_mask, int B, int H, int n, void* stream);
+/* dS = P * (dP - rowsum(dP*P)), in place in dP. */
+int mla_softmax_bwd(const float* P, float* dP, int B, int H, int n, void* stream);
+/* forward_representation token assembly (m3ae.py:342-366): x0[b][0] = cls; x0[b][1+i] = (table[ids[b][i]] if
+ * table else x0[b][1+i]) + pos[i] + type.  x0 is (B, L+1, D). */
+int mla_tokens_assemble(float* x0, const float* table, const int64_t* ids, const float* pos, const float* type,
+                        const float* cls, int B, int L, int D, void* stream);
+/* its gradients: dcls, dtype (needs colsum_all = column sum of dx0 over all B*(L+1) rows) and, for text,
+ * dtable[ids] += dx0 rows (float atomics; dtable pre-zeroed). */
+int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls, float* dtype,
+                            float* dtable, int B, int L, int D, void* stream);
+/* einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)' (basic_model.py:184-186) */
+int mla_patchify(const float* img, float* out, int B, int C, int H, int W, int P, void* stream);
+
 /* ---- torch.optim.SGD(momentum, weight_decay) (main.py:749, 439, 451) ------------------------- */
 /* d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf.  g == NULL means zero gradient
  * (torch-1.8.1 zero_grad semantics).  One flat launch over n contiguous elements. */

@@ -35,6 +35,7 @@ struct IGemmGeom {
   int M;                   // N*OH*OW
   int K;                   // scalar-gather mode: T*C (un-padded flattened K)
   unsigned x_bytes, w_bytes, y_bytes;   // byte sizes of the gathered tensor, the weights and the second operand (wgrad: dY)
+  int epi;                 // 0: MASK = ReLU mask (v = MASK > 0 ? v : 0);  1: MASK = GELU pre-activation u (v *= gelu'(u))
   int tap[MAX_TAPS];       // (dy & 0xff) | (dx & 0xff) << 8 | wt << 16   (int32: read with s_load_dword)
 };
 
@@ -54,6 +55,12 @@ __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned voff, unsigned sof
 }
 __device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+// F.gelu default (erf form), m3ae.py:77, and its derivative
+__device__ __forceinline__ float gelu_fwd(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float u) {
+  return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.39894228040143268f * expf(-0.5f * u * u);
 }
 
 static inline int pack_tap(int dy, int dx, int wt) { return (dy & 0xff) | ((dx & 0xff) << 8) | (wt << 16); }
@@ -96,7 +103,8 @@ __device__ __forceinline__ void mma_kstep(const float* __restrict__ As_w, const 
 template <int BM, int BN, int WM, int WN, bool SCALAR_A>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                         float* Y, const float* R, const float* MASK,
-                                                        float* __restrict__ part, const IGemmGeom g) {
+                                                        float* __restrict__ part, const float* __restrict__ BIAS,
+                                                        float* __restrict__ Y2, const IGemmGeom g) {
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
   constexpr int LDBS = BN;
   constexpr int APASS = BM / 32;            // float4 passes for A (8 float4 per row, 32 rows per pass)
@@ -263,6 +271,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni][e] += rv[e][ni];
     }
+    if (BIAS) {  // Linear bias (one value per output column)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float bv = BIAS[tn * BN + wn * (BN / WN) + ni * 32 + j];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] += bv;
+      }
+    }
     if (MASK) {
       float mv[16][NI];
 #pragma unroll
@@ -272,7 +288,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 16; ++e)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][e] = mv[e][ni] > 0.f ? acc[mi][ni][e] : 0.f;
+        for (int ni = 0; ni < NI; ++ni) {
+          if (g.epi == 0) acc[mi][ni][e] = mv[e][ni] > 0.f ? acc[mi][ni][e] : 0.f;   // ReLU backward
+          else acc[mi][ni][e] *= gelu_grad(mv[e][ni]);                                // GELU backward (erf form)
+        }
+    }
+    if (Y2) {  // second output: GELU of the (bias-added) pre-activation that goes to Y
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          if (ok[e]) Y2[off[e] + ni * 32] = gelu_fwd(acc[mi][ni][e]);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e)
@@ -560,17 +586,18 @@ static int pick_cfg(const long* Ms, const int* weights, int n, int CO, bool scal
 }
 
 static int launch_igemm(const float* X, const float* Wt, float* Y, const float* R, const float* MASK, float* part,
-                        const IGemmGeom& mg, bool scalar, int cfg, hipStream_t st) {
+                        const IGemmGeom& mg, bool scalar, int cfg, hipStream_t st, const float* BIAS = nullptr,
+                        float* Y2 = nullptr) {
   const int total = cdiv(mg.M, cfg_bm(cfg)) * (mg.CO / cfg_bn(cfg));
   if (total <= 0) return MLA_OK;
   if (scalar) {
-    igemm_kernel<256, 64, 4, 1, true><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, mg);
+    igemm_kernel<256, 64, 4, 1, true><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   } else if (cfg == CFG_128x128) {
-    igemm_kernel<128, 128, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, mg);
+    igemm_kernel<128, 128, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   } else if (cfg == CFG_256x64) {
-    igemm_kernel<256, 64, 4, 1, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, mg);
+    igemm_kernel<256, 64, 4, 1, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   } else {
-    igemm_kernel<64, 64, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, mg);
+    igemm_kernel<64, 64, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   }
   MLA_CHECK_LAUNCH("igemm_kernel");
   return MLA_OK;
@@ -714,6 +741,95 @@ extern "C" int mla_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
   } else {
     wgrad_reduce_kernel<1><<<cdiv(n4, 256), 256, 0, st>>>(part, dw, n4, splits);
   }
+  MLA_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return MLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear layers of the transformer encoders (nn.Linear in models/m3ae.py:70-71, 97-98, 308) on the same
+// gather-GEMM: a Linear is a 1-tap "convolution" over token rows.  Rows are addressed as `groups` groups of
+// `rows` consecutive tokens, taken at offset *_off inside groups of *_group_rows tokens, so the sub-range
+// "tokens 1..256 of each 257-token sequence" needs no copy.  w is [K][N] (= nn.Linear.weight transposed).
+// ---------------------------------------------------------------------------------------------
+static int linear_geom(const char* who, IGemmGeom& g, int groups, int rows, int in_group_rows, int in_off,
+                       int out_group_rows, int out_off, int K, int N) {
+  MLA_REQUIRE(groups > 0 && rows > 0 && K > 0 && N > 0, "%s: non-positive dims", who);
+  MLA_REQUIRE(K % 64 == 0 && N % 64 == 0 && K <= 8192 && N <= 8192, "%s: K=%d, N=%d must be multiples of 64", who, K, N);
+  MLA_REQUIRE(in_off >= 0 && in_off + rows <= in_group_rows && out_off >= 0 && out_off + rows <= out_group_rows && in_off < 128,
+              "%s: row window outside its group", who);
+  MLA_REQUIRE((long)groups * in_group_rows * K * 4 < 0xFFFFFFF0L && (long)groups * out_group_rows * N * 4 < 0xFFFFFFF0L,
+              "%s: tensors must be < 4 GiB", who);
+  g = IGemmGeom{};
+  g.N = groups; g.H = in_group_rows; g.W = 1; g.C = K; g.CO = N;
+  g.OH = rows; g.OW = 1; g.sy = g.sx = 1;
+  g.OHF = out_group_rows; g.OWF = 1; g.osy = g.osx = 1; g.ooy = out_off; g.oox = 0;
+  g.T = 1; g.M = groups * rows; g.K = K;
+  g.tap[0] = pack_tap(in_off, 0, 0);
+  g.x_bytes = (unsigned)((size_t)groups * in_group_rows * K * 4);
+  g.w_bytes = (unsigned)((size_t)K * N * 4);
+  return MLA_OK;
+}
+
+extern "C" int mla_linear_fwd(const float* x, const float* w_kn, const float* bias, const float* residual, float* y,
+                              float* y_gelu, int groups, int rows, int x_group_rows, int x_off, int y_group_rows,
+                              int y_off, int K, int N, void* stream) {
+  MLA_REQUIRE(x && w_kn && y, "mla_linear_fwd: null pointer");
+  IGemmGeom g;
+  if (int rc = linear_geom("mla_linear_fwd", g, groups, rows, x_group_rows, x_off, y_group_rows, y_off, K, N)) return rc;
+  const long M = g.M;
+  const int one = 1;
+  return launch_igemm(x, w_kn, y, residual, nullptr, nullptr, g, false, pick_cfg(&M, &one, 1, N, false),
+                      (hipStream_t)stream, bias, y_gelu);
+}
+
+// dx = dy W^T (+ residual) (* gelu'(gelu_src)).  wt_ws: K*N floats.
+extern "C" int mla_linear_dgrad(const float* dy, const float* w_kn, float* dx, const float* residual,
+                                const float* gelu_src, float* wt_ws, int groups, int rows, int dy_group_rows, int dy_off,
+                                int dx_group_rows, int dx_off, int K, int N, void* stream) {
+  MLA_REQUIRE(dy && w_kn && dx && wt_ws, "mla_linear_dgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  weight_transpose_kernel<<<dim3(cdiv(N, 32), cdiv(K, 32), 1), 256, 0, st>>>(w_kn, wt_ws, 1, K, N);
+  MLA_CHECK_LAUNCH("weight_transpose_kernel");
+  IGemmGeom g;   // GEMM: [M][N] x [N][K] -> [M][K]
+  if (int rc = linear_geom("mla_linear_dgrad", g, groups, rows, dy_group_rows, dy_off, dx_group_rows, dx_off, N, K)) return rc;
+  g.epi = 1;
+  const long M = g.M;
+  const int one = 1;
+  return launch_igemm(dy, wt_ws, dx, residual, gelu_src, nullptr, g, false, pick_cfg(&M, &one, 1, K, false), st);
+}
+
+extern "C" size_t mla_linear_wgrad_ws_bytes(int M, int K, int N) {
+  int span, splits;
+  wgrad_plan(M, K, N, 1, &span, &splits);
+  return (size_t)splits * K * N * sizeof(float);
+}
+
+// dw[K][N] = sum_rows x^T dy; x rows at (x_group_rows, x_off), dy rows dense [groups*rows][N].
+extern "C" int mla_linear_wgrad(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows,
+                                int x_off, int K, int N, void* ws, size_t ws_bytes, void* stream) {
+  MLA_REQUIRE(x && dy && dw_kn && ws, "mla_linear_wgrad: null pointer");
+  IGemmGeom g;
+  if (int rc = linear_geom("mla_linear_wgrad", g, groups, rows, x_group_rows, x_off, rows, 0, K, N)) return rc;
+  g.y_bytes = (unsigned)((size_t)g.M * N * 4);
+  hipStream_t st = (hipStream_t)stream;
+  int span, splits;
+  wgrad_plan(g.M, K, N, 1, &span, &splits);
+  const size_t need = (size_t)splits * K * N * sizeof(float);
+  if (ws_bytes < need) {
+    mla_set_error("mla_linear_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    return MLA_ERR_WORKSPACE;
+  }
+  float* part = (float*)ws;
+  if (K % 128 == 0 && N % 128 == 0) {
+    wgrad_kernel<128, 128, 2, 2, false><<<dim3((K / 128) * (N / 128), splits), 256, 0, st>>>(x, dy, part, g, span);
+  } else {
+    wgrad_kernel<64, 64, 2, 2, false><<<dim3((K / 64) * (N / 64), splits), 256, 0, st>>>(x, dy, part, g, span);
+  }
+  MLA_CHECK_LAUNCH("wgrad_kernel");
+  const size_t n4 = (size_t)K * N / 4;
+  if (splits >= 64 || n4 < 16384) wgrad_reduce_kernel<16><<<cdiv(n4, 16), 256, 0, st>>>(part, dw_kn, n4, splits);
+  else if (splits >= 8) wgrad_reduce_kernel<4><<<cdiv(n4, 64), 256, 0, st>>>(part, dw_kn, n4, splits);
+  else wgrad_reduce_kernel<1><<<cdiv(n4, 256), 256, 0, st>>>(part, dw_kn, n4, splits);
   MLA_CHECK_LAUNCH("wgrad_reduce_kernel");
   return MLA_OK;
 }

@@ -85,10 +85,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 }
 
 // x [NB][P][C] -> y [NB][C]; block = (C/4 column groups) x (row lanes), LDS across row lanes.
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int C) {
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int C,
+                                                           int cgpb) {  // cgpb: float4 column groups per block (divides 256 and C/4)
   __shared__ f32x4 red[256];
   const int c4n = C >> 2;
-  const int cgpb = c4n < 256 ? c4n : 256;         // column groups per block
   const int nrl = 256 / cgpb;
   const int cg = blockIdx.y * cgpb + threadIdx.x % cgpb, rl = threadIdx.x / cgpb;
   const int nb = blockIdx.x;
@@ -173,9 +173,11 @@ extern "C" int mla_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, const f
 extern "C" int mla_avgpool_fwd(const float* x, float* y, int NB, int P, int C, void* stream) {
   MLA_REQUIRE(x && y && NB > 0 && P > 0 && C > 0 && C % 4 == 0, "mla_avgpool_fwd: bad argument");
   const int c4n = C / 4;
-  MLA_REQUIRE(c4n >= 256 ? c4n % 256 == 0 : 256 % c4n == 0, "mla_avgpool_fwd: C=%d unsupported", C);
-  dim3 grid(NB, c4n > 256 ? c4n / 256 : 1);
-  avgpool_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, P, C);
+  int cgpb = 256;
+  while (cgpb > 1 && c4n % cgpb != 0) cgpb >>= 1;     // largest power of two <= 256 dividing C/4 (C=768 -> 64)
+  MLA_REQUIRE(cgpb >= 4, "mla_avgpool_fwd: C=%d unsupported", C);
+  dim3 grid(NB, c4n / cgpb);
+  avgpool_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, y, P, C, cgpb);
   MLA_CHECK_LAUNCH("avgpool_fwd_kernel");
   return MLA_OK;
 }

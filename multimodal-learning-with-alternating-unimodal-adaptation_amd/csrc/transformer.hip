@@ -1,0 +1,429 @@
+// Transformer-encoder kernels for the M3AE / CAV-MAE modality encoders (fp32, gfx950).
+//
+//   LayerNorm fwd/bwd             nn.LayerNorm (models/m3ae.py:138, 142, 176; eps 1e-5)
+//   attention                     Attention.forward (models/m3ae.py:102-125): QK^T*scale, where(mask>0,-1e7),
+//                                 softmax, PV -- strided batched GEMMs on v_mfma_f32_32x32x2_f32 that read q/k/v
+//                                 straight out of the (B,n,3,H,64) qkv buffer and write (B,n,D), plus a
+//                                 wave-per-row masked softmax.  The probabilities are materialised (288 GB HBM:
+//                                 2.4 GB per encoder at B=64) and reused by the backward instead of recomputed.
+//   token assembly / embedding    MaskedMultimodalAutoencoder.forward_representation (models/m3ae.py:342-370):
+//                                 [cls] + (patch-linear | text-embedding) + sin-cos position + type embedding
+//   patchify                      einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)' (models/basic_model.py:184-186)
+//   column sums                   bias gradients of the Linear layers
+// The Linear layers themselves run on the gather-GEMM of conv_igemm.hip (mla_linear_*).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, D <= 2048, D % 64 == 0
+// ---------------------------------------------------------------------------------------------------
+template <int PER>   // elements per lane = D / 64 (compile-time so the row lives in registers, not scratch)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ y,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                      float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    v[k] = x[(size_t)row * D + k * 64 + lane];
+    s += v[k];
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const float d = v[k] - mu;
+    q += d * d;
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int c = k * 64 + lane;
+    y[(size_t)row * D + c] = (v[k] - mu) * rs * w[c] + b[c];
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dx += add (residual-branch gradient)
+template <int PER>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* add, float* dx,
+                                                         int M, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float mu = mean[row], rs = rstd[row];
+  float g[PER], xh[PER];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int c = k * 64 + lane;
+    const size_t i = (size_t)row * D + c;
+    g[k] = dy[i] * w[c];
+    xh[k] = (x[i] - mu) * rs;
+    s1 += g[k];
+    s2 += g[k] * xh[k];
+  }
+  s1 = wave_sum(s1) / D;
+  s2 = wave_sum(s2) / D;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const size_t i = (size_t)row * D + k * 64 + lane;
+    float r = rs * (g[k] - s1 - xh[k] * s2);
+    if (add) r += add[i];
+    dx[i] = r;
+  }
+}
+
+// Column reductions over rows.  MODE 0: s0 = sum x.  MODE 1 (LayerNorm affine grads): s0 = sum dy, s1 = sum dy*xhat.
+// grid (C/64, row tiles); 256 threads = 16 float4 column groups x 16 row lanes.
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ partial, int M, int C, int tile_rows) {
+  __shared__ f32x4 red[2][256];
+  const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c4 = blockIdx.x * 16 + cg, c4n = C >> 2;
+  const int r0 = blockIdx.y * tile_rows, r1 = min(M, r0 + tile_rows);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + rl; r < r1; r += 16) {
+    const f32x4 av = reinterpret_cast<const f32x4*>(a)[(size_t)r * c4n + c4];
+    s0 += av;
+    if (MODE == 1) {
+      const f32x4 xv = reinterpret_cast<const f32x4*>(x)[(size_t)r * c4n + c4];
+      s1 += av * ((xv - mean[r]) * rstd[r]);
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < 16; ++k) {
+      s0 += red[0][k * 16 + cg];
+      s1 += red[1][k * 16 + cg];
+    }
+    reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * 2 + 0) * C)[c4] = s0;
+    reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.y * 2 + 1) * C)[c4] = s1;
+  }
+}
+
+// out0[c] = sum_t partial[t][0][c] (fp64), out1[c] = sum_t partial[t][1][c]; one wave per column
+__global__ __launch_bounds__(256) void colreduce_finalize_kernel(const float* __restrict__ partial, int tiles, int C,
+                                                                  float* __restrict__ out0, float* __restrict__ out1) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int t = lane; t < tiles; t += 64) {
+    s += (double)partial[((size_t)t * 2 + 0) * C + c];
+    q += (double)partial[((size_t)t * 2 + 1) * C + c];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane == 0) {
+    out0[c] = (float)s;
+    if (out1) out1[c] = (float)q;
+  }
+}
+
+static int colreduce_tile_rows(int M) {
+  long t = ((long)M + 255) / 256;
+  t = ((t + 15) / 16) * 16;
+  if (t < 64) t = 64;
+  return (int)t;
+}
+extern "C" size_t mla_colreduce_ws_elems(int M, int C) { return (size_t)cdiv(M, colreduce_tile_rows(M)) * 2 * C; }
+
+extern "C" int mla_colsum_rows(const float* x, float* out, float* ws, int M, int C, void* stream) {
+  MLA_REQUIRE(x && out && ws && M > 0 && C > 0 && C % 64 == 0, "mla_colsum_rows: bad argument (C %% 64 == 0)");
+  hipStream_t st = (hipStream_t)stream;
+  const int tr = colreduce_tile_rows(M), nt = cdiv(M, tr);
+  colreduce_kernel<0><<<dim3(C / 64, nt), 256, 0, st>>>(x, nullptr, nullptr, nullptr, ws, M, C, tr);
+  MLA_CHECK_LAUNCH("colreduce_kernel<0>");
+  colreduce_finalize_kernel<<<cdiv(C, 4), 256, 0, st>>>(ws, nt, C, out, nullptr);
+  MLA_CHECK_LAUNCH("colreduce_finalize_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                                 int M, int D, float eps, void* stream) {
+  MLA_REQUIRE(x && w && b && y && mean && rstd && M > 0, "mla_layernorm_fwd: bad argument");
+  MLA_REQUIRE(D == 512 || D == 768 || D == 1024, "mla_layernorm_fwd: D=%d unsupported (512, 768, 1024)", D);
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 512) ln_fwd_kernel<8><<<cdiv(M, 4), 256, 0, st>>>(x, w, b, y, mean, rstd, M, D, eps);
+  else if (D == 768) ln_fwd_kernel<12><<<cdiv(M, 4), 256, 0, st>>>(x, w, b, y, mean, rstd, M, D, eps);
+  else ln_fwd_kernel<16><<<cdiv(M, 4), 256, 0, st>>>(x, w, b, y, mean, rstd, M, D, eps);
+  MLA_CHECK_LAUNCH("ln_fwd_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                                 const float* add, float* dx, float* dw, float* db, float* ws, int M, int D, void* stream) {
+  MLA_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && ws && M > 0, "mla_layernorm_bwd: bad argument");
+  MLA_REQUIRE(D == 512 || D == 768 || D == 1024, "mla_layernorm_bwd: D=%d unsupported (512, 768, 1024)", D);
+  hipStream_t st = (hipStream_t)stream;
+  const int tr = colreduce_tile_rows(M), nt = cdiv(M, tr);
+  colreduce_kernel<1><<<dim3(D / 64, nt), 256, 0, st>>>(dy, x, mean, rstd, ws, M, D, tr);
+  MLA_CHECK_LAUNCH("colreduce_kernel<1>");
+  colreduce_finalize_kernel<<<cdiv(D, 4), 256, 0, st>>>(ws, nt, D, db, dw);
+  MLA_CHECK_LAUNCH("colreduce_finalize_kernel");
+  // dx may alias dy or add (each row is fully read into registers before it is written)
+  if (D == 512) ln_bwd_dx_kernel<8><<<cdiv(M, 4), 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, M, D);
+  else if (D == 768) ln_bwd_dx_kernel<12><<<cdiv(M, 4), 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, M, D);
+  else ln_bwd_dx_kernel<16><<<cdiv(M, 4), 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, M, D);
+  MLA_CHECK_LAUNCH("ln_bwd_dx_kernel");
+  return MLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Strided batched GEMM (attention): C[z][i][j] = alpha * sum_k A[z][i][k] * B[z][k][j], z = (b, h).
+// 64x64 tile, 4 waves x one 32x32 MFMA tile, K step 32 through LDS; arbitrary element strides, so q/k/v
+// are read in place from the (B,n,3,H,hd) qkv buffer and results land directly in their final layout.
+// ---------------------------------------------------------------------------------------------------
+struct BGemmDesc {
+  int M, N, K, H;                       // per-batch dims, heads per batch (z = b*H + h)
+  long a_b, a_h, a_i, a_k;              // element strides of A: batch, head, row i, reduction k
+  long b_b, b_h, b_k, b_j;
+  long c_b, c_h, c_i, c_j;
+  float alpha;
+};
+
+__global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                     float* __restrict__ C, const BGemmDesc d) {
+  __shared__ __attribute__((aligned(16))) float As[64 * 36];
+  __shared__ float Bs[32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z, b = z / d.H, h = z - b * d.H;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const float* Ab = A + b * d.a_b + h * d.a_h;
+  const float* Bb = B + b * d.b_b + h * d.b_h;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  // A tile element (r, kk): thread -> kk = tid & 31, r = (tid >> 5) + 8 p.  B tile (kk, c): c = tid & 63, kk = (tid >> 6) + 4 p.
+  for (int k0 = 0; k0 < d.K; k0 += 32) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int r = i0 + (tid >> 5) + 8 * p, kk = k0 + (tid & 31);
+      av[p] = (r < d.M && kk < d.K) ? Ab[r * d.a_i + kk * d.a_k] : 0.f;
+      const int kb = k0 + (tid >> 6) + 4 * p, c = j0 + (tid & 63);
+      bv[p] = (kb < d.K && c < d.N) ? Bb[kb * d.b_k + c * d.b_j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      As[((tid >> 5) + 8 * p) * 36 + (tid & 31)] = av[p];
+      Bs[((tid >> 6) + 4 * p) * 64 + (tid & 63)] = bv[p];
+    }
+    __syncthreads();
+    const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + i) * 36 + kk * 8 + 4 * hh]);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], Bs[(kk * 8 + 4 * hh + jj) * 64 + wn * 32 + i], acc, 0, 0, 0);
+    }
+  }
+  float* Cb = C + b * d.c_b + h * d.c_h;
+  const int hh = lane >> 5, j = j0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = i0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+    if (i < d.M && j < d.N) Cb[i * d.c_i + j * d.c_j] = acc[e] * d.alpha;
+  }
+}
+
+extern "C" int mla_bgemm(const float* A, const float* B, float* C, int batches, int heads, int M, int N, int K,
+                         const long* a_strides, const long* b_strides, const long* c_strides, float alpha, void* stream) {
+  MLA_REQUIRE(A && B && C && a_strides && b_strides && c_strides, "mla_bgemm: null pointer");
+  MLA_REQUIRE(batches > 0 && heads > 0 && M > 0 && N > 0 && K > 0 && (long)batches * heads < 65536, "mla_bgemm: bad dims");
+  BGemmDesc d;
+  d.M = M; d.N = N; d.K = K; d.H = heads; d.alpha = alpha;
+  d.a_b = a_strides[0]; d.a_h = a_strides[1]; d.a_i = a_strides[2]; d.a_k = a_strides[3];
+  d.b_b = b_strides[0]; d.b_h = b_strides[1]; d.b_k = b_strides[2]; d.b_j = b_strides[3];
+  d.c_b = c_strides[0]; d.c_h = c_strides[1]; d.c_i = c_strides[2]; d.c_j = c_strides[3];
+  bgemm_kernel<<<dim3(cdiv(N, 64), cdiv(M, 64), batches * heads), 256, 0, (hipStream_t)stream>>>(A, B, C, d);
+  MLA_CHECK_LAUNCH("bgemm_kernel");
+  return MLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked softmax over the last axis of S (B, H, n, n), in place; wave per row; n <= 1024
+// mask: pm (B, n) float, pm > 0 -> score replaced by -1e7 (models/m3ae.py:111-117)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, const float* __restrict__ pm, int rows,
+                                                           int n, int rows_per_batch) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* s = S + (size_t)row * n;
+  const float* m = pm ? pm + (size_t)(row / rows_per_batch) * n : nullptr;
+  float v[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int j = k * 64 + lane;
+    float t = -INFINITY;
+    if (j < n) {
+      t = s[j];
+      if (m && m[j] > 0.f) t = -1e7f;
+    }
+    v[k] = t;
+    mx = fmaxf(mx, t);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    v[k] = (k * 64 + lane < n) ? expf(v[k] - mx) : 0.f;
+    sum += v[k];
+  }
+  const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k * 64 + lane < n) s[k * 64 + lane] = v[k] * inv;
+}
+
+// dS = P * (dP - sum_j dP*P), in place in dP
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, int rows, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* p = P + (size_t)row * n;
+  float* g = dP + (size_t)row * n;
+  float pv[16], gv[16];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int j = k * 64 + lane;
+    pv[k] = j < n ? p[j] : 0.f;
+    gv[k] = j < n ? g[j] : 0.f;
+    dot += pv[k] * gv[k];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k * 64 + lane < n) g[k * 64 + lane] = pv[k] * (gv[k] - dot);
+}
+
+extern "C" int mla_softmax_fwd(float* S, const float* pad_mask, int B, int H, int n, void* stream) {
+  MLA_REQUIRE(S && B > 0 && H > 0 && n > 0 && n <= 1024, "mla_softmax_fwd: bad argument (n <= 1024)");
+  const long rows = (long)B * H * n;
+  MLA_REQUIRE(rows < (1L << 31), "mla_softmax_fwd: too many rows");
+  softmax_fwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(S, pad_mask, (int)rows, n, H * n);
+  MLA_CHECK_LAUNCH("softmax_fwd_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_softmax_bwd(const float* P, float* dP, int B, int H, int n, void* stream) {
+  MLA_REQUIRE(P && dP && B > 0 && H > 0 && n > 0 && n <= 1024, "mla_softmax_bwd: bad argument (n <= 1024)");
+  const long rows = (long)B * H * n;
+  softmax_bwd_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(P, dP, (int)rows, n);
+  MLA_CHECK_LAUNCH("softmax_bwd_kernel");
+  return MLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// token assembly:  x0[b][0] = cls;  x0[b][1+i] = (table[ids[b][i]] | x0[b][1+i] (already holds the patch Linear))
+//                                                 + pos[i] + type
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_kernel(float* __restrict__ x0, const float* __restrict__ table,
+                                                        const int64_t* __restrict__ ids, const float* __restrict__ pos,
+                                                        const float* __restrict__ type, const float* __restrict__ cls,
+                                                        int B, int L, int D) {
+  const int d4n = D >> 2;
+  const size_t total = (size_t)B * (L + 1) * d4n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % d4n);
+    const size_t r = i / d4n;
+    const int t = (int)(r % (L + 1));
+    const size_t b = r / (L + 1);
+    f32x4 v;
+    if (t == 0) {
+      v = reinterpret_cast<const f32x4*>(cls)[c];
+    } else {
+      if (table) v = reinterpret_cast<const f32x4*>(table)[(size_t)ids[b * L + t - 1] * d4n + c];
+      else v = reinterpret_cast<const f32x4*>(x0)[i];
+      v += reinterpret_cast<const f32x4*>(pos)[(size_t)(t - 1) * d4n + c] + reinterpret_cast<const f32x4*>(type)[c];
+    }
+    reinterpret_cast<f32x4*>(x0)[i] = v;
+  }
+}
+
+// Gradients of the assembly: dcls[d] = sum_b dx0[b][0][d]; dtype[d] = sum_{b,t>=1} dx0[b][t][d] (given the
+// all-row column sum `tot`: dtype = tot - dcls); text: dtable[ids[b][i]] += dx0[b][1+i] (float atomics: the
+// only order-dependent sum in the library; dtable must be zeroed by the caller).
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx0, const float* __restrict__ tot,
+                                                            const int64_t* __restrict__ ids, float* __restrict__ dcls,
+                                                            float* __restrict__ dtype, float* __restrict__ dtable, int B,
+                                                            int L, int D) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+  if (gid < (size_t)D) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx0[(size_t)b * (L + 1) * D + gid];
+    dcls[gid] = s;
+    dtype[gid] = tot[gid] - s;
+  }
+  if (dtable) {
+    const size_t total = (size_t)B * L * D;
+    for (size_t i = gid; i < total; i += gsz) {
+      const int d = (int)(i % D);
+      const size_t r = i / D;
+      const size_t b = r / L, t = r % L;
+      atomicAdd(&dtable[(size_t)ids[r] * D + d], dx0[(b * (L + 1) + t + 1) * D + d]);
+    }
+  }
+}
+
+extern "C" int mla_tokens_assemble(float* x0, const float* table, const int64_t* ids, const float* pos, const float* type,
+                                   const float* cls, int B, int L, int D, void* stream) {
+  MLA_REQUIRE(x0 && pos && type && cls && B > 0 && L > 0 && D % 4 == 0 && ((table == nullptr) == (ids == nullptr)),
+              "mla_tokens_assemble: bad argument");
+  size_t blocks = ((size_t)B * (L + 1) * (D / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  assemble_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x0, table, ids, pos, type, cls, B, L, D);
+  MLA_CHECK_LAUNCH("assemble_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls,
+                                       float* dtype, float* dtable, int B, int L, int D, void* stream) {
+  MLA_REQUIRE(dx0 && colsum_all && dcls && dtype && B > 0 && L > 0 && D > 0 && ((dtable == nullptr) == (ids == nullptr)),
+              "mla_tokens_assemble_bwd: bad argument");
+  size_t blocks = dtable ? ((size_t)B * L * D + 255) / 256 : (size_t)cdiv(D, 256);
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < (size_t)cdiv(D, 256)) blocks = cdiv(D, 256);
+  assemble_bwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(dx0, colsum_all, ids, dcls, dtype, dtable, B, L, D);
+  MLA_CHECK_LAUNCH("assemble_bwd_kernel");
+  return MLA_OK;
+}
+
+// einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)': out[b][h*GW+w][c*P*P + p1*P + p2] = img[b][c][h*P+p1][w*P+p2]
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int C,
+                                                        int Himg, int Wimg, int P) {
+  const int GW = Wimg / P, GH = Himg / P, F = C * P * P;
+  const size_t total = (size_t)B * GH * GW * F;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    size_t r = i / F;
+    const int w = (int)(r % GW); r /= GW;
+    const int h = (int)(r % GH);
+    const size_t b = r / GH;
+    const int p2 = f % P, p1 = (f / P) % P, c = f / (P * P);
+    out[i] = img[((b * C + c) * Himg + h * P + p1) * Wimg + w * P + p2];
+  }
+}
+
+extern "C" int mla_patchify(const float* img, float* out, int B, int C, int H, int W, int P, void* stream) {
+  MLA_REQUIRE(img && out && B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0, "mla_patchify: bad argument");
+  size_t blocks = ((size_t)B * C * H * W + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  patchify_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(img, out, B, C, H, W, P);
+  MLA_CHECK_LAUNCH("patchify_kernel");
+  return MLA_OK;
+}

@@ -47,6 +47,20 @@ PROTOTYPES = {
     "mla_gs_ws_elems": (_Z, [_I, _I]),
     "mla_gs_project": (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),
     "mla_sgd_step": (_I, [_P, _P, _P, _Z, _F, _F, _F, _I, _P]),
+    "mla_linear_fwd": (_I, [_P] * 6 + [_I] * 8 + [_P]),
+    "mla_linear_dgrad": (_I, [_P] * 6 + [_I] * 8 + [_P]),
+    "mla_linear_wgrad_ws_bytes": (_Z, [_I, _I, _I]),
+    "mla_linear_wgrad": (_I, [_P, _P, _P] + [_I] * 6 + [_P, _Z, _P]),
+    "mla_colreduce_ws_elems": (_Z, [_I, _I]),
+    "mla_colsum_rows": (_I, [_P, _P, _P, _I, _I, _P]),
+    "mla_layernorm_fwd": (_I, [_P] * 6 + [_I, _I, _F, _P]),
+    "mla_layernorm_bwd": (_I, [_P] * 10 + [_I, _I, _P]),
+    "mla_bgemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P]),
+    "mla_softmax_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mla_softmax_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mla_tokens_assemble": (_I, [_P] * 6 + [_I, _I, _I, _P]),
+    "mla_tokens_assemble_bwd": (_I, [_P] * 6 + [_I, _I, _I, _P]),
+    "mla_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

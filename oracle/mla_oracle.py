@@ -436,3 +436,175 @@ def mla_step(st: MLAState, spec: torch.Tensor, image: torch.Tensor, label: torch
 
     out["loss"] = loss * av_alpha + loss_v * (1 - av_alpha)      # main.py:472 (Q8)
     return out
+
+
+# ======================================================================================
+# M3AE modality encoder: models/m3ae.py:48-179 (blocks), 181-223 (sin-cos),
+# 300-370 (MaskedMultimodalAutoencoder.forward_representation); models/basic_model.py:182-200
+# (M3AEClassifier.forward).  Functional restatement on torch-CPU ops; gradients by autograd (the reference
+# uses autograd too, and there are no ReLU/max-pool decisions to flip here).  DropPath == identity (Q10).
+# Parameter dict uses the reference's state_dict keys and layouts (nn.Linear.weight is (out, in)).
+# ======================================================================================
+def sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:            # m3ae.py:181-194
+    omega = np.arange(embed_dim // 2, dtype=np.float32)
+    omega /= embed_dim / 2.
+    omega = 1. / 10000 ** omega
+    out = np.einsum('m,d->md', pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_pos_embed_1d(embed_dim: int, length: int) -> torch.Tensor:    # m3ae.py:197-203
+    return torch.from_numpy(sincos_1d(embed_dim, np.arange(length, dtype=np.float32)).astype(np.float32))
+
+
+def sincos_pos_embed_2d(embed_dim: int, length: int) -> torch.Tensor:    # m3ae.py:206-223 ("w goes first")
+    gs = int(length ** 0.5)
+    assert gs * gs == length
+    grid = np.stack(np.meshgrid(np.arange(gs, dtype=np.float32), np.arange(gs, dtype=np.float32)), axis=0)
+    grid = grid.reshape([2, 1, gs, gs])
+    emb = np.concatenate([sincos_1d(embed_dim // 2, grid[0]), sincos_1d(embed_dim // 2, grid[1])], axis=1)
+    return torch.from_numpy(emb.astype(np.float32))
+
+
+def m3ae_param_names(depth: int) -> List[str]:
+    names = ["text_embedding.weight", "image_embedding.weight", "image_embedding.bias",
+             "encoder_image_type_embedding", "encoder_text_type_embedding", "cls_token"]
+    for i in range(depth):
+        b = f"encoder.blocks.{i}."
+        names += [b + "layer_norm1.weight", b + "layer_norm1.bias", b + "attention.qkv_linear.weight",
+                  b + "attention.qkv_linear.bias", b + "attention.fc.weight", b + "attention.fc.bias",
+                  b + "layer_norm2.weight", b + "layer_norm2.bias", b + "transformer_mlp.fc1.weight",
+                  b + "transformer_mlp.fc1.bias", b + "transformer_mlp.fc2.weight", b + "transformer_mlp.fc2.bias"]
+    return names + ["encoder.layer_norm.weight", "encoder.layer_norm.bias"]
+
+
+def make_m3ae_params(seed: int, depth: int = 12, emb: int = 768, vocab: int = 30522, patch_dim: int = 768) -> Dict[str, torch.Tensor]:
+    shapes = {"text_embedding.weight": (vocab, emb), "image_embedding.weight": (emb, patch_dim), "image_embedding.bias": (emb,),
+              "encoder_image_type_embedding": (1, 1, emb), "encoder_text_type_embedding": (1, 1, emb), "cls_token": (1, 1, emb)}
+    p: Dict[str, torch.Tensor] = {}
+    for si, name in enumerate(m3ae_param_names(depth)):
+        if name in shapes:
+            shp = shapes[name]
+        elif name.endswith("qkv_linear.weight"):
+            shp = (3 * emb, emb)
+        elif name.endswith("qkv_linear.bias"):
+            shp = (3 * emb,)
+        elif name.endswith("fc1.weight"):
+            shp = (4 * emb, emb)
+        elif name.endswith("fc1.bias"):
+            shp = (4 * emb,)
+        elif name.endswith("fc2.weight"):
+            shp = (emb, 4 * emb)
+        elif name.endswith("weight") and "layer_norm" not in name:
+            shp = (emb, emb)
+        else:
+            shp = (emb,)
+        if "layer_norm" in name and name.endswith("weight"):
+            p[name] = portable_normal(seed, shp, stream=2000 + si, mean=1.0, std=0.05)
+        elif name == "text_embedding.weight":
+            p[name] = portable_normal(seed, shp, stream=2000 + si, std=1.0)              # m3ae.py:307 normal_(0,1)
+        elif len(shp) == 2:
+            p[name] = portable_normal(seed, shp, stream=2000 + si, std=(2.0 / (shp[0] + shp[1])) ** 0.5)
+        else:
+            p[name] = portable_normal(seed, shp, stream=2000 + si, std=0.02)
+    return p
+
+
+def patchify(image: torch.Tensor, p: int = 16) -> torch.Tensor:
+    """einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)' (basic_model.py:184-186)."""
+    B, C, H, W = image.shape
+    x = image.reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5)
+    return x.reshape(B, (H // p) * (W // p), C * p * p)
+
+
+def m3ae_block(p, pre: str, x: torch.Tensor, padding_mask: Optional[torch.Tensor], heads: int) -> torch.Tensor:
+    B, n, D = x.shape
+    h = F.layer_norm(x, (D,), p[pre + "layer_norm1.weight"], p[pre + "layer_norm1.bias"])          # m3ae.py:146
+    qkv = F.linear(h, p[pre + "attention.qkv_linear.weight"], p[pre + "attention.qkv_linear.bias"])
+    qkv = qkv.view(B, n, 3, heads, D // heads).permute(2, 0, 3, 1, 4)                                # :104-106
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = torch.matmul(q, k.transpose(-2, -1)) * ((D // heads) ** -0.5)                             # :109
+    if padding_mask is not None:
+        pm = padding_mask[:, None, None, :].expand(att.shape)
+        att = torch.where(pm > 0, torch.tensor(-1e7), att)                                          # :111-117
+    att = F.softmax(att, dim=-1)
+    o = torch.matmul(att, v).permute(0, 2, 1, 3).reshape(B, n, D)                                   # :121-122
+    x = x + F.linear(o, p[pre + "attention.fc.weight"], p[pre + "attention.fc.bias"])               # :123, 149
+    h = F.layer_norm(x, (D,), p[pre + "layer_norm2.weight"], p[pre + "layer_norm2.bias"])
+    h = F.gelu(F.linear(h, p[pre + "transformer_mlp.fc1.weight"], p[pre + "transformer_mlp.fc1.bias"]))   # :76-77
+    return x + F.linear(h, p[pre + "transformer_mlp.fc2.weight"], p[pre + "transformer_mlp.fc2.bias"])     # :79, 154
+
+
+def m3ae_forward_representation(p, image_patches=None, text=None, text_padding_mask=None, heads: int = 12, depth: Optional[int] = None):
+    """m3ae.py:342-370, device-free.  Exactly one of image_patches (B,L,768) / text (B,L) int64 is given
+    (MLA runs each modality through its own M3AE).  Returns the (B, 1+L, D) representation."""
+    D = p["cls_token"].shape[-1]
+    if depth is None:
+        depth = sum(1 for k in p if k.endswith("layer_norm1.weight"))
+    B = image_patches.shape[0] if image_patches is not None else text.shape[0]
+    xs = [p["cls_token"].expand(B, 1, D)]
+    pms = [torch.zeros((B, 1))]
+    if image_patches is not None:
+        L = image_patches.shape[1]
+        xs.append(F.linear(image_patches, p["image_embedding.weight"], p["image_embedding.bias"])
+                  + sincos_pos_embed_2d(D, L)[None] + p["encoder_image_type_embedding"])
+        pms.append(torch.zeros((B, L)))
+    if text is not None:
+        L = text.shape[1]
+        xs.append(F.embedding(text, p["text_embedding.weight"]) + sincos_pos_embed_1d(D, L)[None]
+                  + p["encoder_text_type_embedding"])
+        pms.append(text_padding_mask)
+    x = torch.cat(xs, dim=1)
+    pm = torch.cat(pms, dim=1)
+    for i in range(depth):
+        x = m3ae_block(p, f"encoder.blocks.{i}.", x, pm, heads)
+    return F.layer_norm(x, (D,), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"])      # m3ae.py:176
+
+
+def m3ae_feature(p, image=None, token=None, padding_mask=None, heads: int = 12):
+    """M3AEClassifier.forward for one modality (basic_model.py:182-200): token mean over ALL 1+L positions."""
+    if image is not None:
+        return m3ae_forward_representation(p, image_patches=patchify(image), heads=heads).mean(dim=1)
+    return m3ae_forward_representation(p, text=token.squeeze(1), text_padding_mask=padding_mask.squeeze(1), heads=heads).mean(dim=1)
+
+
+class M3AEState:
+    def __init__(self, text: Dict[str, torch.Tensor], image: Dict[str, torch.Tensor], head: Dict[str, torch.Tensor]):
+        self.text, self.image, self.head = text, image, head
+        self.mom: Dict[str, Dict[str, torch.Tensor]] = {"text": {}, "image": {}, "head": {}}
+        self.Pl = torch.eye(head["weight"].shape[1])
+        self.exp_count = 0
+
+
+def mla_step_m3ae(st: M3AEState, token, padding_mask, image, label, batch_index: int, len_dataloader: int,
+                  lr: float = 1e-3, momentum: float = 0.9, wd: float = 1e-4, gs_mode: str = "as_intended",
+                  heads: int = 12) -> dict:
+    """main.py:419-476 with args.lorb == 'm3ae' (a = text modality via mae_a, v = image via mae_v; main.py:426)."""
+    out: dict = {}
+
+    def phase(name, params, feat_fn):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        W = st.head["weight"].clone().requires_grad_(True)
+        b = st.head["bias"].clone().requires_grad_(True)
+        feat = feat_fn(leaves)
+        logits = feat @ W.t() + b
+        loss = F.cross_entropy(logits, label)
+        keys = list(leaves)
+        grads = torch.autograd.grad(loss, [leaves[k] for k in keys] + [W, b], allow_unused=True)
+        g = {k: gv for k, gv in zip(keys, grads[:-2]) if gv is not None}     # unused params: grad None -> SGD skips them
+        dW, db = grads[-2], grads[-1]
+        out["feat_" + name], out["out_" + name], out["loss_" + name] = feat.detach(), logits.detach(), loss.detach()
+        out[f"head_grad_{name}_raw"] = dW.clone()
+        st.Pl, dWp = gs_before_update(st.Pl, feat.detach(), dW, batch_index, len_dataloader, st.exp_count, gs_mode)
+        out[f"head_grad_{name}"], out["grads_" + name] = dWp, g
+        mom = st.mom["text" if name == "a" else "image"]
+        for k, gv in g.items():
+            params[k], mom[k] = sgd_step(params[k], gv, mom.get(k), lr, momentum, wd)
+        for k, gv in (("weight", dWp), ("bias", db)):
+            st.head[k], st.mom["head"][k] = sgd_step(st.head[k], gv, st.mom["head"].get(k), lr, momentum, wd)
+        st.exp_count += 1
+
+    phase("a", st.text, lambda p: m3ae_feature(p, token=token, padding_mask=padding_mask, heads=heads))
+    phase("v", st.image, lambda p: m3ae_feature(p, image=image, heads=heads))
+    out["loss"] = out["loss_a"] * 0.55 + out["loss_v"] * 0.45
+    return out
