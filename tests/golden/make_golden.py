@@ -323,8 +323,12 @@ def run_m3ae_case(tag, B, depth, vocab, n_classes, steps, seed):
         for k in ("feat_a", "feat_v", "out_a", "out_v", "loss_a", "loss_v", "head_grad_a_raw", "head_grad_v_raw",
                   "head_grad_a", "head_grad_v"):
             # projected gradients: the element-wise denominator alpha + k_i r_j of utils/utils.py:36 (Q2) can be
-            # close to 0, which amplifies fp32 re-association (measured 7e-4 relative at D=768) -> 2e-3
-            close(f"s{s}.{k}", orc[k], rec[k], rtol=2e-3 if k in ("head_grad_a", "head_grad_v") else 2e-4, atol=2e-6)
+            # close to 0, which amplifies fp32 re-association (measured up to 2.2e-4 absolute at D=768) -> they are
+            # held to the north-star tolerance, 1e-3 absolute
+            if k in ("head_grad_a", "head_grad_v"):
+                close(f"s{s}.{k}", orc[k], rec[k], rtol=0.0, atol=1e-3)
+            else:
+                close(f"s{s}.{k}", orc[k], rec[k], rtol=2e-4, atol=2e-6)
             fx[f"s{s}.{k}"] = rec[k].numpy()
         for name in ("a", "v"):
             assert set(orc["grads_" + name]) == set(rec["grads_" + name]), "set of parameters that receive a gradient"
@@ -338,7 +342,7 @@ def run_m3ae_case(tag, B, depth, vocab, n_classes, steps, seed):
                 close_l2(f"s{s}.state.{nm}.{k}", params[k], sd[k], tol=1e-5)
             fx[f"s{s}.{nm}.cls_token"] = sd["cls_token"].numpy().copy()
             fx[f"s{s}.{nm}.fc2w.head"] = sd[f"encoder.blocks.{depth - 1}.transformer_mlp.fc2.weight"].flatten()[:64].numpy().copy()
-        close(f"s{s}.Pl", st.Pl, gs.Pl.detach(), rtol=2e-3, atol=1e-7)
+        close(f"s{s}.Pl", st.Pl, gs.Pl.detach(), rtol=0.0, atol=1e-4)
         fx[f"s{s}.head.weight"] = fc.weight.detach().numpy().copy()
         for k, vv in pl_digest(gs.Pl).items():
             fx[f"s{s}.Pl.{k}"] = np.asarray(vv)
