@@ -1,0 +1,358 @@
+"""M3AE modality encoder on the HIP kernels (reference: models/m3ae.py:48-179, 300-370;
+models/basic_model.py:127-200 M3AEClassifier).
+
+One `M3AEEncoder` per modality, like the reference's `mae_a` (text) / `mae_v` (image): pre-LN ViT-B
+(emb 768, 12 heads, mlp x4) over [cls] + 256 tokens, token-mean feature.  DropPath == identity (SURVEY Q10:
+the published DropPath returns None).  Same host design as the ResNet encoder: ONE flat fp32 buffer for the
+parameters that receive gradients (Linear weights stored [in][out] = the GEMM B operand), one for gradients,
+explicit forward/backward launch plans over a workspace allocated once; attention probabilities are kept
+(not recomputed) for the backward.  Parameters the modality never touches (the image embedding of the text
+encoder and vice versa) live outside the flat buffer: their gradient is None in the reference, so SGD skips them.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import MLAHipError
+
+
+def _sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:                      # m3ae.py:181-194
+    omega = np.arange(embed_dim // 2, dtype=np.float32)
+    omega /= embed_dim / 2.
+    omega = 1. / 10000 ** omega
+    out = np.einsum('m,d->md', pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_pos_embed(embed_dim: int, length: int, two_d: bool) -> torch.Tensor:
+    """get_1d_sincos_pos_embed / get_2d_sincos_pos_embed (m3ae.py:197-223), without the leading 1."""
+    if not two_d:
+        emb = _sincos_1d(embed_dim, np.arange(length, dtype=np.float32))
+    else:
+        gs = int(length ** 0.5)
+        if gs * gs != length:
+            raise MLAHipError("2-D position embedding needs a square patch grid")
+        grid = np.stack(np.meshgrid(np.arange(gs, dtype=np.float32), np.arange(gs, dtype=np.float32)), axis=0)   # w first
+        grid = grid.reshape([2, 1, gs, gs])
+        emb = np.concatenate([_sincos_1d(embed_dim // 2, grid[0]), _sincos_1d(embed_dim // 2, grid[1])], axis=1)
+    return torch.from_numpy(emb.astype(np.float32))
+
+
+class M3AEEncoder:
+    BLOCK_PARAMS = [("layer_norm1.weight", "D"), ("layer_norm1.bias", "D"), ("attention.qkv_linear.weight", "D,3D"),
+                    ("attention.qkv_linear.bias", "3D"), ("attention.fc.weight", "D,D"), ("attention.fc.bias", "D"),
+                    ("layer_norm2.weight", "D"), ("layer_norm2.bias", "D"), ("transformer_mlp.fc1.weight", "D,4D"),
+                    ("transformer_mlp.fc1.bias", "4D"), ("transformer_mlp.fc2.weight", "4D,D"), ("transformer_mlp.fc2.bias", "D")]
+
+    def __init__(self, kind: str, device="cuda", depth: int = 12, emb_dim: int = 768, num_heads: int = 12,
+                 text_vocab_size: int = 30522, patch_dim: int = 768, seed: Optional[int] = None):
+        if kind not in ("text", "image"):
+            raise ValueError("kind must be 'text' or 'image'")
+        self.kind, self.device = kind, torch.device(device)
+        self.depth, self.D, self.H, self.V, self.PD = depth, emb_dim, num_heads, text_vocab_size, patch_dim
+        D = emb_dim
+        dims = {"D": (D,), "3D": (3 * D,), "4D": (4 * D,), "D,3D": (D, 3 * D), "D,D": (D, D), "D,4D": (D, 4 * D), "4D,D": (4 * D, D)}
+        # ---- flat layout of the parameters this modality trains (Linear weights as [in][out])
+        lay: List[Tuple[str, Tuple[int, ...]]] = []
+        if kind == "text":
+            lay += [("text_embedding.weight", (text_vocab_size, D)), ("encoder_text_type_embedding", (D,))]
+        else:
+            lay += [("image_embedding.weight", (patch_dim, D)), ("image_embedding.bias", (D,)), ("encoder_image_type_embedding", (D,))]
+        lay.append(("cls_token", (D,)))
+        for i in range(depth):
+            lay += [(f"encoder.blocks.{i}.{n}", dims[s]) for n, s in self.BLOCK_PARAMS]
+        lay += [("encoder.layer_norm.weight", (D,)), ("encoder.layer_norm.bias", (D,))]
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for name, shp in lay:
+            self.layout[name] = (off, shp)
+            off += math.prod(shp)
+        self.numel = off
+        f32 = dict(device=self.device, dtype=torch.float32)
+        self.flat = torch.zeros(off, **f32)
+        self.grad = torch.zeros(off, **f32)
+        self.p = {k: self.flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
+        self.g = {k: self.grad[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
+        # ---- parameters of the other modality's input path: never used, never receive a gradient (kept for state_dict)
+        if kind == "text":
+            self.unused = {"image_embedding.weight": torch.zeros((patch_dim, D), **f32), "image_embedding.bias": torch.zeros(D, **f32),
+                           "encoder_image_type_embedding": torch.zeros(D, **f32)}
+        else:
+            self.unused = {"text_embedding.weight": torch.zeros((text_vocab_size, D), **f32),
+                           "encoder_text_type_embedding": torch.zeros(D, **f32)}
+        self._pos: Dict[int, torch.Tensor] = {}
+        self._ws: dict = {}
+        self._key = None
+        self.reset_parameters(seed)
+
+    # ------------------------------------------------------------------------------------------
+    def reset_parameters(self, seed: Optional[int] = None) -> None:
+        """Module-default initialisation of the reference (m3ae.py:306-324; nn.Linear / nn.LayerNorm defaults)."""
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed) if seed is not None else gen.seed()
+        for name, (_o, shp) in self.layout.items():
+            t = self.p[name]
+            if name == "text_embedding.weight":
+                t.copy_(torch.randn(shp, generator=gen))                                   # normal_(0, 1)
+            elif name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding"):
+                t.copy_(torch.randn(shp, generator=gen) + 0.02)                            # torch.empty().normal_(0.02): mean .02, std 1
+            elif "layer_norm" in name:
+                t.fill_(1.0 if name.endswith("weight") else 0.0)
+            elif len(shp) == 2:
+                bound = math.sqrt(6.0 / (shp[0] + shp[1])) if name == "image_embedding.weight" else 1.0 / math.sqrt(shp[0])
+                t.copy_((torch.rand(shp, generator=gen) * 2 - 1) * bound)
+            else:   # nn.Linear bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                fan_in = 4 * self.D if name.endswith("fc2.bias") else (self.PD if name == "image_embedding.bias" else self.D)
+                t.copy_((torch.rand(shp, generator=gen) * 2 - 1) / math.sqrt(fan_in))
+
+    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
+        """Reference keys and layouts (nn.Linear.weight is (out, in); type embeddings / cls are (1,1,D))."""
+        sd = {}
+        for name in self.layout:
+            t = self.p[name]
+            if name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding"):
+                sd[prefix + name] = t.clone().view(1, 1, -1)
+            elif t.dim() == 2 and name != "text_embedding.weight":
+                sd[prefix + name] = t.t().contiguous()
+            else:
+                sd[prefix + name] = t.clone()
+        for name, t in self.unused.items():
+            if name.endswith("type_embedding"):
+                sd[prefix + name] = t.clone().view(1, 1, -1)
+            elif name == "image_embedding.weight":
+                sd[prefix + name] = t.t().contiguous()
+            else:
+                sd[prefix + name] = t.clone()
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
+        for name in list(self.layout) + list(self.unused):
+            if prefix + name not in sd:
+                if strict:
+                    raise KeyError(f"missing key {prefix + name}")
+                continue
+            src = sd[prefix + name].to(self.device, torch.float32)
+            dst = self.p[name] if name in self.layout else self.unused[name]
+            if src.dim() == 3:
+                src = src.reshape(-1)
+            elif src.dim() == 2 and name != "text_embedding.weight":
+                src = src.t()
+            dst.copy_(src)
+
+    def grads_as_reference(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for name in self.layout:
+            t = self.g[name]
+            if name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding"):
+                out[name] = t.clone().view(1, 1, -1)
+            elif t.dim() == 2 and name != "text_embedding.weight":
+                out[name] = t.t().contiguous()
+            else:
+                out[name] = t.clone()
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def _plan(self, B: int, L: int) -> dict:
+        if self._key == (B, L):
+            return self._ws
+        D, H, n = self.D, self.H, L + 1
+        M = B * n
+        f32 = dict(device=self.device, dtype=torch.float32)
+        ws: dict = {"B": B, "L": L, "n": n, "M": M}
+        ws["x0"] = torch.empty((M, D), **f32)
+        ws["blocks"] = []
+        for _ in range(self.depth):
+            ws["blocks"].append({"h1": torch.empty((M, D), **f32), "qkv": torch.empty((M, 3 * D), **f32),
+                                 "P": torch.empty((B, H, n, n), **f32), "o": torch.empty((M, D), **f32),
+                                 "xmid": torch.empty((M, D), **f32), "h2": torch.empty((M, D), **f32),
+                                 "u": torch.empty((M, 4 * D), **f32), "gl": torch.empty((M, 4 * D), **f32),
+                                 "xout": torch.empty((M, D), **f32),
+                                 "st": torch.empty((4, M), **f32)})          # mean1, rstd1, mean2, rstd2
+        ws["y"] = torch.empty((M, D), **f32)
+        ws["stf"] = torch.empty((2, M), **f32)
+        ws["feat"] = torch.empty((B, D), **f32)
+        if self.kind == "image":
+            ws["patches"] = torch.empty((B * L, self.PD), **f32)
+        ws["pos"] = sincos_pos_embed(D, L, two_d=(self.kind == "image")).to(self.device)
+        self._ws, self._key = ws, (B, L)
+        return ws
+
+    def _bwd_ws(self, ws: dict) -> None:
+        if "dA" in ws:
+            return
+        D, H, n, M, B = self.D, self.H, ws["n"], ws["M"], ws["B"]
+        f32 = dict(device=self.device, dtype=torch.float32)
+        ws["dA"], ws["dB"], ws["dC"] = (torch.empty((M, D), **f32) for _ in range(3))
+        ws["du"] = torch.empty((M, 4 * D), **f32)
+        ws["dqkv"] = torch.empty((M, 3 * D), **f32)
+        ws["dP"] = torch.empty((B, H, n, n), **f32)
+        ws["wt_ws"] = torch.empty(4 * D * D, **f32)
+        wb = max(ops.linear_wgrad_ws_bytes(M, D, 3 * D), ops.linear_wgrad_ws_bytes(M, D, 4 * D), ops.linear_wgrad_ws_bytes(M, 4 * D, D),
+                 ops.linear_wgrad_ws_bytes(M, D, D), ops.linear_wgrad_ws_bytes(B * ws["L"], self.PD, D))
+        ws["wgrad_ws"] = torch.empty((wb + 3) // 4, **f32)
+        ws["red_ws"] = torch.empty(ops.colreduce_ws_elems(M, 4 * D), **f32)
+        ws["colsum"] = torch.empty(D, **f32)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inp: torch.Tensor, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """text: inp = token ids (B,1,L) or (B,L) int64, padding_mask (B,1,L)/(B,L) float (1 = padded);
+        image: inp = (B,3,256,256) fp32.  Returns the (B, D) token-mean feature (basic_model.py:182-200)."""
+        st = ops.cur_stream()
+        D, H = self.D, self.H
+        hd = D // H
+        if self.kind == "text":
+            ids = inp.reshape(inp.shape[0], -1).contiguous()                                 # token.squeeze(1)
+            B, L = ids.shape
+            ws = self._plan(B, L)
+            pm = padding_mask.reshape(B, -1).to(torch.float32)
+            ws["ids"] = ids
+            ws["pm"] = torch.cat([torch.zeros((B, 1), device=self.device), pm], dim=1).contiguous()   # cls is never masked (m3ae.py:347)
+            ops.tokens_assemble(ws["x0"], self.p["text_embedding.weight"], ids, ws["pos"], self.p["encoder_text_type_embedding"],
+                                self.p["cls_token"], B, L, D, stream=st)
+        else:
+            B = inp.shape[0]
+            L = (inp.shape[2] // 16) * (inp.shape[3] // 16)
+            ws = self._plan(B, L)
+            ws["pm"] = None
+            ops.patchify(inp.contiguous(), ws["patches"], 16, stream=st)                     # basic_model.py:184-186
+            ops.linear_fwd(ws["patches"], self.p["image_embedding.weight"], self.p["image_embedding.bias"], ws["x0"], B, L,
+                           self.PD, D, y_group_rows=L + 1, y_off=1, stream=st)               # m3ae.py:353
+            ops.tokens_assemble(ws["x0"], None, None, ws["pos"], self.p["encoder_image_type_embedding"], self.p["cls_token"],
+                                B, L, D, stream=st)
+        n, M = ws["n"], ws["M"]
+        scale = hd ** -0.5
+        x = ws["x0"]
+        for i, bk in enumerate(ws["blocks"]):
+            P_ = lambda nm: self.p[f"encoder.blocks.{i}.{nm}"]
+            bk["x"] = x
+            ops.layernorm_fwd(x, P_("layer_norm1.weight"), P_("layer_norm1.bias"), bk["h1"], bk["st"][0], bk["st"][1], M, D, stream=st)
+            ops.linear_fwd(bk["h1"], P_("attention.qkv_linear.weight"), P_("attention.qkv_linear.bias"), bk["qkv"], 1, M, D, 3 * D, stream=st)
+            qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
+            ops.bgemm(bk["qkv"], bk["qkv"], bk["P"], B, H, n, n, hd, qs, (n * 3 * D, hd, 1, 3 * D), ss, scale, b_off=D, stream=st)   # m3ae.py:109
+            ops.softmax_fwd(bk["P"], ws["pm"], B, H, n, stream=st)                                                                    # :111-118
+            ops.bgemm(bk["P"], bk["qkv"], bk["o"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), os_, 1.0, b_off=2 * D, stream=st)   # :121-122
+            ops.linear_fwd(bk["o"], P_("attention.fc.weight"), P_("attention.fc.bias"), bk["xmid"], 1, M, D, D, residual=x, stream=st)  # :123,149
+            ops.layernorm_fwd(bk["xmid"], P_("layer_norm2.weight"), P_("layer_norm2.bias"), bk["h2"], bk["st"][2], bk["st"][3], M, D, stream=st)
+            ops.linear_fwd(bk["h2"], P_("transformer_mlp.fc1.weight"), P_("transformer_mlp.fc1.bias"), bk["u"], 1, M, D, 4 * D,
+                           y_gelu=bk["gl"], stream=st)                                                                               # :76-77
+            ops.linear_fwd(bk["gl"], P_("transformer_mlp.fc2.weight"), P_("transformer_mlp.fc2.bias"), bk["xout"], 1, M, 4 * D, D,
+                           residual=bk["xmid"], stream=st)                                                                            # :79,154
+            x = bk["xout"]
+        ws["xlast"] = x
+        ops.layernorm_fwd(x, self.p["encoder.layer_norm.weight"], self.p["encoder.layer_norm.bias"], ws["y"], ws["stf"][0], ws["stf"][1],
+                          M, D, stream=st)                                                                                            # m3ae.py:176
+        ops.avgpool_fwd(ws["y"], ws["feat"], B, n, D, stream=st)                              # .mean(dim=1) over all 1+L tokens
+        self._pa = n
+        return ws["feat"]
+
+    # ------------------------------------------------------------------------------------------
+    def backward_from_pooled(self, dfeat: torch.Tensor, P: Optional[int] = None) -> None:
+        ws = self._ws
+        self._bwd_ws(ws)
+        st = ops.cur_stream()
+        D, H, n, M, B, L = self.D, self.H, ws["n"], ws["M"], ws["B"], ws["L"]
+        hd = D // H
+        scale = hd ** -0.5
+        dA, dB_, dC = ws["dA"], ws["dB"], ws["dC"]
+        red, wtw, wgw = ws["red_ws"], ws["wt_ws"], ws["wgrad_ws"]
+        ops.avgpool_bwd(dfeat.contiguous(), dA, B, n, D, stream=st)                                             # d y
+        ops.layernorm_bwd(dA, ws["xlast"], self.p["encoder.layer_norm.weight"], ws["stf"][0], ws["stf"][1], dA,
+                          self.g["encoder.layer_norm.weight"], self.g["encoder.layer_norm.bias"], red, M, D, stream=st)
+        dx = dA                                                                                                 # grad wrt block output
+        for i in reversed(range(self.depth)):
+            bk = ws["blocks"][i]
+            P_ = lambda nm: self.p[f"encoder.blocks.{i}.{nm}"]
+            G_ = lambda nm: self.g[f"encoder.blocks.{i}.{nm}"]
+            # ---- MLP: xout = xmid + fc2(gelu(fc1(LN2(xmid))))
+            ops.colsum_rows(dx, G_("transformer_mlp.fc2.bias"), red, M, D, stream=st)
+            ops.linear_wgrad(bk["gl"], dx, G_("transformer_mlp.fc2.weight"), wgw, 1, M, 4 * D, D, stream=st)
+            ops.linear_dgrad(dx, P_("transformer_mlp.fc2.weight"), ws["du"], wtw, 1, M, 4 * D, D, gelu_src=bk["u"], stream=st)
+            ops.colsum_rows(ws["du"], G_("transformer_mlp.fc1.bias"), red, M, 4 * D, stream=st)
+            ops.linear_wgrad(bk["h2"], ws["du"], G_("transformer_mlp.fc1.weight"), wgw, 1, M, D, 4 * D, stream=st)
+            ops.linear_dgrad(ws["du"], P_("transformer_mlp.fc1.weight"), dB_, wtw, 1, M, D, 4 * D, stream=st)   # d h2
+            ops.layernorm_bwd(dB_, bk["xmid"], P_("layer_norm2.weight"), bk["st"][2], bk["st"][3], dB_, G_("layer_norm2.weight"),
+                              G_("layer_norm2.bias"), red, M, D, add=dx, stream=st)                             # d xmid -> dB_
+            # ---- attention: xmid = x + fc(PV)
+            ops.colsum_rows(dB_, G_("attention.fc.bias"), red, M, D, stream=st)
+            ops.linear_wgrad(bk["o"], dB_, G_("attention.fc.weight"), wgw, 1, M, D, D, stream=st)
+            ops.linear_dgrad(dB_, P_("attention.fc.weight"), dC, wtw, 1, M, D, D, stream=st)                    # d o (B,n,D)
+            qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
+            ops.bgemm(dC, bk["qkv"], ws["dP"], B, H, n, n, hd, os_, (n * 3 * D, hd, 1, 3 * D), ss, 1.0, b_off=2 * D, stream=st)          # dP = dO V^T
+            ops.bgemm(bk["P"], dC, ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * D, hd, D, 1), qs, 1.0, c_off=2 * D, stream=st)   # dV = P^T dO
+            ops.softmax_bwd(bk["P"], ws["dP"], B, H, n, stream=st)                                                                       # dS
+            ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), qs, scale, b_off=D, stream=st)     # dQ = s dS K
+            ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * 3 * D, hd, 3 * D, 1), qs, scale,
+                      c_off=D, stream=st)                                                                                                # dK = s dS^T Q
+            ops.colsum_rows(ws["dqkv"], G_("attention.qkv_linear.bias"), red, M, 3 * D, stream=st)
+            ops.linear_wgrad(bk["h1"], ws["dqkv"], G_("attention.qkv_linear.weight"), wgw, 1, M, D, 3 * D, stream=st)
+            ops.linear_dgrad(ws["dqkv"], P_("attention.qkv_linear.weight"), dC, wtw, 1, M, D, 3 * D, stream=st)  # d h1
+            ops.layernorm_bwd(dC, bk["x"], P_("layer_norm1.weight"), bk["st"][0], bk["st"][1], dC, G_("layer_norm1.weight"),
+                              G_("layer_norm1.bias"), red, M, D, add=dB_, stream=st)                            # d x -> dC
+            dx, dC = dC, dx                                                                                     # rotate buffers
+            ws["dA"], ws["dC"] = dx, dC
+        # ---- token assembly (m3ae.py:342-366)
+        ops.colsum_rows(dx, ws["colsum"], red, M, D, stream=st)
+        if self.kind == "text":
+            self.g["text_embedding.weight"].zero_()
+            ops.tokens_assemble_bwd(dx, ws["colsum"], ws["ids"], self.g["cls_token"], self.g["encoder_text_type_embedding"],
+                                    self.g["text_embedding.weight"], B, L, D, stream=st)
+        else:
+            ops.tokens_assemble_bwd(dx, ws["colsum"], None, self.g["cls_token"], self.g["encoder_image_type_embedding"], None,
+                                    B, L, D, stream=st)
+            dimg = dx.view(B, n, D)[:, 1:, :].contiguous().view(B * L, D)       # memory plumbing: drop the cls rows
+            ops.colsum_rows(dimg, self.g["image_embedding.bias"], red, B * L, D, stream=st)
+            ops.linear_wgrad(ws["patches"], dimg, self.g["image_embedding.weight"], wgw, 1, B * L, self.PD, D, stream=st)
+
+
+class M3AEClassifier:
+    """models/basic_model.py:127-200 under --gs_flag: mae_a (text) + mae_v (image) + ConcatFusion(768 -> C)."""
+
+    def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None):
+        from .model import ConcatFusion, N_CLASSES
+        fusion = getattr(args, "fusion_method", "concat")
+        dataset = getattr(args, "dataset", "Food101")
+        if dataset not in ("MVSA", "Food101", "CREMAD"):                            # basic_model.py:132-144
+            raise NotImplementedError("Incorrect dataset name {}".format(dataset))
+        if fusion != "concat":                                                      # basic_model.py:146-163
+            raise NotImplementedError("Incorrect fusion method: {}!".format(fusion))
+        if not getattr(args, "gs_flag", False):
+            raise NotImplementedError("mla_hip implements the --gs_flag (MLA) path only")
+        self.args, self.device = args, torch.device(device)
+        s = (lambda k: None if seed is None else seed + k)
+        self.fusion_module = ConcatFusion(768, N_CLASSES[dataset], device, s(2))   # basic_model.py:149
+        self.mae_a = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(0))    # :166
+        self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1))   # :167
+        self.module = self
+
+    def mla_encoders(self):
+        return [("a", "text", self.mae_a), ("v", "image", self.mae_v)]
+
+    def forward(self, token: torch.Tensor, padding_mask: torch.Tensor, visual: torch.Tensor):
+        """a, v = model(token, padding_mask, image)  (main.py:426; basic_model.py:182-200)."""
+        a = self.mae_a.forward(token, padding_mask)
+        v = self.mae_v.forward(visual)
+        return a, v
+
+    __call__ = forward
+
+    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
+        sd = {}
+        sd.update(self.fusion_module.fc_out.state_dict(prefix + "fusion_module.fc_out."))
+        sd.update(self.mae_a.state_dict(prefix + "mae_a."))
+        sd.update(self.mae_v.state_dict(prefix + "mae_v."))
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        if any(k.startswith("module.") for k in sd):
+            sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        self.mae_a.load_state_dict(sd, "mae_a.", strict)
+        self.mae_v.load_state_dict(sd, "mae_v.", strict)
+        if "fusion_module.fc_out.weight" in sd:
+            self.fusion_module.fc_out.load_state_dict(sd, "fusion_module.fc_out.")
+        elif strict:
+            raise KeyError("missing key fusion_module.fc_out.weight")

@@ -96,6 +96,10 @@ class AVClassifier:
         self.module = self                                                  # `model.module.` paths (DataParallel, main.py:432)
         self._feat: Dict[int, dict] = {}
 
+    def mla_encoders(self):
+        """(phase tag, optimiser group name, encoder) in the order main.py:432-454 alternates over them."""
+        return [("a", "audio", self.audio_net), ("v", "visual", self.visual_net)]
+
     def train(self, mode: bool = True):
         if not mode:
             raise NotImplementedError("eval-mode BatchNorm is outside the MLA training path (SURVEY section 8f-1)")
@@ -118,9 +122,9 @@ class AVClassifier:
         n, h, w, c = fa.shape
         ops.avgpool_fwd(fa, buf["a"], B, h * w, c)                           # adaptive_avg_pool2d + flatten
         nt, hv, wv, cv = fv.shape
-        self._pv = (nt // B) * hv * wv
-        self._pa = h * w
-        ops.avgpool_fwd(fv, buf["v"], B, self._pv, cv)                       # regroup T + adaptive_avg_pool3d + flatten
+        self.audio_net._pa = h * w                                           # pooled pixels per sample (for the backward)
+        self.visual_net._pa = (nt // B) * hv * wv
+        ops.avgpool_fwd(fv, buf["v"], B, self.visual_net._pa, cv)            # regroup T + adaptive_avg_pool3d + flatten
         return buf["a"], buf["v"]
 
     __call__ = forward

@@ -235,3 +235,83 @@ def gs_project(Pl, r, G, alpha: float, ws, stream: Optional[int] = None) -> None
 def sgd_step(p, g, buf, lr: float, momentum: float, wd: float, first: bool, stream: Optional[int] = None) -> None:
     check(_lib.load().mla_sgd_step(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, wd, int(first),
                                    stream or cur_stream()), "mla_sgd_step")
+
+
+# ---- transformer encoders (M3AE / CAV-MAE) -----------------------------------------------------------
+LN_EPS = 1e-5     # nn.LayerNorm default (models/m3ae.py:138)
+
+
+def linear_fwd(x, w_kn, bias, y, groups: int, rows: int, K: int, N: int, x_group_rows: Optional[int] = None, x_off: int = 0,
+               y_group_rows: Optional[int] = None, y_off: int = 0, residual=None, y_gelu=None, stream: Optional[int] = None):
+    """y[g][y_off+r] = x[g][x_off+r] @ w_kn (+bias) (+residual); y_gelu (optional) also receives gelu(y)."""
+    check(_lib.load().mla_linear_fwd(_p(x), _p(w_kn), _p(bias), _p(residual), _p(y), _p(y_gelu), groups, rows,
+                                     x_group_rows or rows, x_off, y_group_rows or rows, y_off, K, N,
+                                     stream or cur_stream()), "mla_linear_fwd")
+
+
+def linear_dgrad(dy, w_kn, dx, wt_ws, groups: int, rows: int, K: int, N: int, residual=None, gelu_src=None,
+                 stream: Optional[int] = None):
+    """dx = dy @ w_kn^T (+residual) (* gelu'(gelu_src)); dense rows."""
+    check(_lib.load().mla_linear_dgrad(_p(dy), _p(w_kn), _p(dx), _p(residual), _p(gelu_src), _p(wt_ws), groups, rows,
+                                       rows, 0, rows, 0, K, N, stream or cur_stream()), "mla_linear_dgrad")
+
+
+def linear_wgrad_ws_bytes(M: int, K: int, N: int) -> int:
+    return int(_lib.load().mla_linear_wgrad_ws_bytes(M, K, N))
+
+
+def linear_wgrad(x, dy, dw_kn, ws, groups: int, rows: int, K: int, N: int, x_group_rows: Optional[int] = None, x_off: int = 0,
+                 stream: Optional[int] = None):
+    check(_lib.load().mla_linear_wgrad(_p(x), _p(dy), _p(dw_kn), groups, rows, x_group_rows or rows, x_off, K, N, _p(ws),
+                                       ws.numel() * ws.element_size(), stream or cur_stream()), "mla_linear_wgrad")
+
+
+def colreduce_ws_elems(M: int, C: int) -> int:
+    return int(_lib.load().mla_colreduce_ws_elems(M, C))
+
+
+def colsum_rows(x, out, ws, M: int, C: int, stream: Optional[int] = None):
+    check(_lib.load().mla_colsum_rows(_p(x), _p(out), _p(ws), M, C, stream or cur_stream()), "mla_colsum_rows")
+
+
+def layernorm_fwd(x, w, b, y, mean, rstd, M: int, D: int, eps: float = LN_EPS, stream: Optional[int] = None):
+    check(_lib.load().mla_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), M, D, eps, stream or cur_stream()),
+          "mla_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dx, dw, db, ws, M: int, D: int, add=None, stream: Optional[int] = None):
+    check(_lib.load().mla_layernorm_bwd(_p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(add), _p(dx), _p(dw), _p(db), _p(ws),
+                                        M, D, stream or cur_stream()), "mla_layernorm_bwd")
+
+
+def bgemm(A, B, C, batches: int, heads: int, M: int, N: int, K: int, a_strides, b_strides, c_strides, alpha: float = 1.0,
+          a_off: int = 0, b_off: int = 0, c_off: int = 0, stream: Optional[int] = None):
+    """C[z] = alpha * A[z] @ B[z]; strides in elements (batch, head, row, col-or-k); *_off: element offsets into the buffers."""
+    L4 = ctypes.c_long * 4
+    sa, sb, sc = L4(*a_strides), L4(*b_strides), L4(*c_strides)      # keep alive across the call (no temporaries!)
+    pa, pb, pc = _p(A) + 4 * a_off, _p(B) + 4 * b_off, _p(C) + 4 * c_off
+    check(_lib.load().mla_bgemm(pa, pb, pc, batches, heads, M, N, K, ctypes.addressof(sa), ctypes.addressof(sb),
+                                ctypes.addressof(sc), alpha, stream or cur_stream()), "mla_bgemm")
+
+
+def softmax_fwd(S, pad_mask, B: int, H: int, n: int, stream: Optional[int] = None):
+    check(_lib.load().mla_softmax_fwd(_p(S), _p(pad_mask), B, H, n, stream or cur_stream()), "mla_softmax_fwd")
+
+
+def softmax_bwd(P, dP, B: int, H: int, n: int, stream: Optional[int] = None):
+    check(_lib.load().mla_softmax_bwd(_p(P), _p(dP), B, H, n, stream or cur_stream()), "mla_softmax_bwd")
+
+
+def tokens_assemble(x0, table, ids, pos, type_emb, cls, B: int, L: int, D: int, stream: Optional[int] = None):
+    check(_lib.load().mla_tokens_assemble(_p(x0), _p(table), _p(ids, torch.int64), _p(pos), _p(type_emb), _p(cls), B, L, D,
+                                          stream or cur_stream()), "mla_tokens_assemble")
+
+
+def tokens_assemble_bwd(dx0, colsum_all, ids, dcls, dtype, dtable, B: int, L: int, D: int, stream: Optional[int] = None):
+    check(_lib.load().mla_tokens_assemble_bwd(_p(dx0), _p(colsum_all), _p(ids, torch.int64), _p(dcls), _p(dtype), _p(dtable),
+                                              B, L, D, stream or cur_stream()), "mla_tokens_assemble_bwd")
+
+
+def patchify(img, out, P: int = 16, stream: Optional[int] = None):
+    B, C, H, W = img.shape
+    check(_lib.load().mla_patchify(_p(img), _p(out), B, C, H, W, P, stream or cur_stream()), "mla_patchify")

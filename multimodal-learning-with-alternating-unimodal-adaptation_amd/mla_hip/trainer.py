@@ -20,34 +20,39 @@ import torch
 
 from . import ops
 from .dist import Comm
-from .model import AVClassifier
 from .optim import FusedSGD
 from .plugin import GSPlugin
 
 
 class MLATrainer:
-    def __init__(self, model: AVClassifier, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-4,
+    def __init__(self, model, lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-4,
                  gs_mode: str = "as_intended", legacy_zero_grad: bool = False, av_alpha: float = 0.55,
                  comm: Optional[Comm] = None):
+        """`model`: AVClassifier (ResNet-18 audio+visual) or M3AEClassifier (text+image); anything exposing
+        `mla_encoders()`, `forward(*inputs) -> features` and `fusion_module.fc_out`."""
         self.model = model
         self.head = model.fusion_module.fc_out
+        self.encoders = model.mla_encoders()                    # [(tag, group, encoder)], alternation order
         self.gs_plugin = GSPlugin(dim=self.head.in_features, device=model.device, mode=gs_mode)
-        self.optimizer = FusedSGD({"audio": model.audio_net, "visual": model.visual_net, "head": self.head},
-                                  lr, momentum, weight_decay, legacy_zero_grad)
+        groups = {grp: enc for _t, grp, enc in self.encoders}
+        groups["head"] = self.head
+        self.optimizer = FusedSGD(groups, lr, momentum, weight_decay, legacy_zero_grad)
         self.av_alpha = av_alpha
         self.comm = comm if comm is not None else Comm()
         dev = model.device
         self._colsum = torch.empty(self.head.in_features, device=dev, dtype=torch.float32)
         self._msg = torch.empty(self.head.numel + self.head.in_features + 1, device=dev, dtype=torch.float32)
-        self.losses = {k: torch.zeros(1, device=dev, dtype=torch.float32) for k in ("loss", "loss_a", "loss_v")}
+        self.losses = {k: torch.zeros(1, device=dev, dtype=torch.float32) for k in ["loss"] + ["loss_" + t for t, _g, _e in self.encoders]}
         self.last = {}
 
-    def _phase(self, name: str, enc, feat: torch.Tensor, pooled_px: int, label: torch.Tensor, inv_batch: float,
+    keep_debug = False
+
+    def _phase(self, name: str, enc, feat: torch.Tensor, label: torch.Tensor, inv_batch: float,
                batch_step: int, len_dataloader: int, pending: list):
         logits, loss, dX = self.head.forward_backward(feat, label, inv_batch, slot=name)               # :432-435
         self.last["out_" + name] = logits
         self.losses["loss_" + name].copy_(loss)
-        enc.backward_from_pooled(dX, pooled_px)                                               # loss.backward()
+        enc.backward_from_pooled(dX, enc._pa)                                                 # loss.backward()
         works = self.comm.allreduce_flat_async(enc.grad)                                     # overlaps what follows
         fires = self.gs_plugin.mode == "as_intended" and self.gs_plugin.exp_count != 0
         r_mean = None
@@ -55,50 +60,62 @@ class MLATrainer:
             ops.colsum(feat, self._colsum, inv_batch)
             self.comm.exchange_head(self.head.grad, self._colsum, self.losses["loss_" + name], self._msg)
             r_mean = self._colsum
-        self.last[f"head_grad_{name}_raw"] = self.head.weight_grad.clone() if self.keep_debug else None
+        if self.keep_debug:      # test hooks: inputs of the projection (it is ill-conditioned, tests re-evaluate it in fp64)
+            self.last[f"head_grad_{name}_raw"] = self.head.weight_grad.clone()
+            self.last[f"Pl_before_{name}"] = self.gs_plugin.Pl.clone()
+            self.last[f"r_mean_{name}"] = None if r_mean is None else r_mean.clone()
         if fires:
             self.gs_plugin.before_update(self.head, feat, batch_step, len_dataloader, self.gs_plugin.exp_count,
                                          r_mean=r_mean)                                       # :437-438
+        if self.keep_debug:
+            self.last[f"head_grad_{name}"] = self.head.weight_grad.clone()
         opt = self.optimizer
         opt.mark_ready("head")
         opt.step_group("head")                                                                # optimizer.step(): head
         pending.append((name, works))
         self.gs_plugin.exp_count += 1                                                         # :442
 
-    keep_debug = False
-
-    def train_step(self, spec: torch.Tensor, image: torch.Tensor, label: torch.Tensor, batch_step: int,
-                   len_dataloader: int):
-        """spec (B,H,W) or (B,1,H,W); image (B,3,T,H,W); label int64 (B,).  Returns device scalars
+    def train_step(self, *batch):
+        """AVClassifier:   train_step(spec, image, label, batch_step, len_dataloader)
+        M3AEClassifier: train_step(token, padding_mask, image, label, batch_step, len_dataloader)
+        spec (B,H,W) or (B,1,H,W); image (B,3,T,H,W) / (B,3,256,256); label int64 (B,).  Returns device scalars
         {'loss','loss_a','loss_v'} (no host sync; call .item() when needed, main.py:472-476)."""
+        *inputs, label, batch_step, len_dataloader = batch
         m, opt = self.model, self.optimizer
-        if spec.dim() == 3:
-            spec = spec.unsqueeze(1)                                                          # main.py:431
-        B = spec.shape[0]
+        if len(inputs) == 2:                                                                  # ResNet audio+visual
+            spec, image = inputs
+            if spec.dim() == 3:
+                spec = spec.unsqueeze(1)                                                      # main.py:431
+            inputs = (spec.float(), image.float())
+        B = label.shape[0]
         inv_batch = 1.0 / (B * self.comm.world)
         opt.zero_grad()                                                                       # main.py:164
-        a, v = m.forward(spec.float(), image.float())                                         # main.py:431
-        self.last["a"], self.last["v"] = a, v
+        feats = m.forward(*inputs)                                                            # main.py:424-431 (joint forward, Q7)
         pending: list = []
-        # ---- audio phase.  Its encoder SGD is deferred until its all-reduce has landed; the visual
-        # phase does not read audio parameters, so enqueueing it first changes no result.
-        self._phase("a", m.audio_net, a, m._pa, label, inv_batch, batch_step, len_dataloader, pending)
-        opt.mark_ready("audio")
-        if not self.comm.active:
-            opt.step_group("audio")
-        opt_legacy_audio = opt.legacy_zero_grad
-        # ---- visual phase
-        self._phase("v", m.visual_net, v, m._pv, label, inv_batch, batch_step, len_dataloader, pending)
-        opt.mark_ready("visual")
+        n_enc = len(self.encoders)
+        for k, ((tag, grp, enc), feat) in enumerate(zip(self.encoders, feats)):
+            self.last[tag] = feat
+            # Encoder SGD: immediately when single-process; with data parallelism it is deferred until that
+            # encoder's all-reduce has landed (later phases never read an earlier encoder's parameters, so
+            # enqueueing them first changes no result).
+            self._phase(tag, enc, feat, label, inv_batch, batch_step, len_dataloader, pending)
+            opt.mark_ready(grp)
+            if not self.comm.active:
+                opt.step_group(grp)
+                if opt.legacy_zero_grad:          # torch 1.8.1: earlier encoders hold zero (not None) grads in later steps (Q6)
+                    for _t2, g2, _e2 in self.encoders[:k]:
+                        opt.grad_state[g2] = "zero"
+                        opt.step_group(g2)
         if self.comm.active:
-            self.comm.wait(pending[0][1])
-            opt.step_group("audio")
-            self.comm.wait(pending[1][1])
-        if opt_legacy_audio:                      # torch 1.8.1: audio grads are zero (not None) in the visual step (Q6)
-            opt.grad_state["audio"] = "zero"
-            opt.step_group("audio")
-        opt.step_group("visual")
+            for k, (tag, grp, enc) in enumerate(self.encoders):
+                self.comm.wait(pending[k][1])
+                opt.step_group(grp)
+                if opt.legacy_zero_grad:
+                    for _t2, g2, _e2 in self.encoders[:k]:
+                        opt.grad_state[g2] = "zero"
+                        opt.step_group(g2)
         opt.drop_grads()                                                                      # main.py:468-470
-        torch.add(self.losses["loss_a"] * self.av_alpha, self.losses["loss_v"], alpha=1 - self.av_alpha,
+        t0, t1 = self.encoders[0][0], self.encoders[1][0]
+        torch.add(self.losses["loss_" + t0] * self.av_alpha, self.losses["loss_" + t1], alpha=1 - self.av_alpha,
                   out=self.losses["loss"])                                                    # main.py:472 (Q8)
         return self.losses

@@ -1,0 +1,283 @@
+"""M3AE row: transformer kernels and the text+image MLA step, HIP vs oracle / reference golden.
+
+fp32.  Per-kernel tolerances 2e-5 relative to max|ref| (GEMM-like) / 1e-5 (element-wise); encoder-level gradients
+relL2 <= 1e-4 (smooth network: no ReLU / max-pool decisions to flip); step-level features, logits, losses and raw
+head gradients 2e-4 absolute; projected head gradient 1e-3 absolute (north star) because the reference's
+element-wise denominator (Q2) is ill-conditioned on mixed-sign transformer features (tests/golden/make_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mla_oracle as O  # noqa: E402
+from util import assert_close  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mla_hip import ops as _ops
+    return _ops
+
+
+def rel_l2(got, want):
+    got, want = torch.as_tensor(got).double().cpu(), torch.as_tensor(want).double().cpu()
+    return ((got - want).norm() / max(want.norm().item(), 1e-30)).item()
+
+
+@pytest.mark.parametrize("groups,rows,xg,xo,yg,yo,K,N", [(1, 771, 771, 0, 771, 0, 768, 2304), (3, 256, 256, 0, 257, 1, 768, 768),
+                                                          (2, 5, 9, 3, 7, 2, 64, 128), (1, 300, 300, 0, 300, 0, 3072, 768)])
+def test_linear_fwd_dgrad_wgrad(ops, groups, rows, xg, xo, yg, yo, K, N):
+    seed = groups + rows + K
+    x = O.portable_normal(seed, (groups, xg, K), stream=1)
+    w = O.portable_normal(seed, (N, K), stream=2, std=K ** -0.5)             # reference layout (out, in)
+    b = O.portable_normal(seed, (N,), stream=3, std=0.1)
+    res = O.portable_normal(seed, (groups, yg, N), stream=4)
+    xs = x[:, xo:xo + rows]
+    u_ref = F.linear(xs, w, b)
+    w_kn = w.t().contiguous().cuda()
+    y = torch.full((groups, yg, N), 7.0, device="cuda")
+    yg_ = torch.empty_like(y)
+    ops.linear_fwd(x.cuda(), w_kn, b.cuda(), y, groups, rows, K, N, x_group_rows=xg, x_off=xo, y_group_rows=yg, y_off=yo, y_gelu=yg_)
+    assert_close(y[:, yo:yo + rows], u_ref, atol=0, rtol=2e-5, name="linear fwd")
+    assert_close(yg_[:, yo:yo + rows], F.gelu(u_ref), atol=1e-6, rtol=2e-5, name="linear fwd gelu output")
+    if yo > 0:
+        assert torch.all(y[:, :yo] == 7.0), "rows outside the window must stay untouched"
+    y2 = torch.empty((groups, yg, N), device="cuda")
+    ops.linear_fwd(x.cuda(), w_kn, b.cuda(), y2, groups, rows, K, N, x_group_rows=xg, x_off=xo, y_group_rows=yg, y_off=yo, residual=res.cuda())
+    assert_close(y2[:, yo:yo + rows], u_ref + res[:, yo:yo + rows], atol=0, rtol=2e-5, name="linear fwd + residual")
+    # backward (dense rows)
+    M = groups * rows
+    dy = O.portable_normal(seed, (M, N), stream=5)
+    usrc = O.portable_normal(seed, (M, K), stream=6)
+    addr = O.portable_normal(seed, (M, K), stream=7)
+    dx_ref = dy @ w
+    gp = 0.5 * (1 + torch.erf(usrc / 2 ** 0.5)) + usrc * torch.exp(-0.5 * usrc ** 2) / (2 * np.pi) ** 0.5
+    wt = torch.empty(K * N, device="cuda")
+    dx = torch.empty((M, K), device="cuda")
+    ops.linear_dgrad(dy.cuda(), w_kn, dx, wt, 1, M, K, N)
+    assert_close(dx, dx_ref, atol=0, rtol=2e-5, name="linear dgrad")
+    ops.linear_dgrad(dy.cuda(), w_kn, dx, wt, 1, M, K, N, residual=addr.cuda(), gelu_src=usrc.cuda())
+    assert_close(dx, (dx_ref + addr) * gp, atol=1e-6, rtol=2e-5, name="linear dgrad + residual, * gelu'")
+    dw = torch.empty((K, N), device="cuda")
+    ws = torch.empty(ops.linear_wgrad_ws_bytes(M, K, N) // 4 + 4, device="cuda")
+    ops.linear_wgrad(x.cuda(), dy.cuda(), dw, ws, groups, rows, K, N, x_group_rows=xg, x_off=xo)
+    assert_close(dw, xs.reshape(M, K).t() @ dy, atol=0, rtol=2e-5, name="linear wgrad")
+    db = torch.empty(N, device="cuda")
+    ops.colsum_rows(dy.cuda(), db, torch.empty(ops.colreduce_ws_elems(M, N), device="cuda"), M, N)
+    assert_close(db, dy.sum(0), atol=1e-5, rtol=1e-5, name="bias grad (colsum_rows)")
+
+
+@pytest.mark.parametrize("M,D", [(771, 768), (5, 768), (1000, 512), (130, 1024)])
+def test_layernorm(ops, M, D):
+    x = O.portable_normal(M, (M, D), stream=1, mean=0.3, std=1.7).requires_grad_(True)
+    w = O.portable_normal(M, (D,), stream=2, mean=1.0, std=0.2).requires_grad_(True)
+    b = O.portable_normal(M, (D,), stream=3, std=0.2).requires_grad_(True)
+    dy = O.portable_normal(M, (M, D), stream=4)
+    add = O.portable_normal(M, (M, D), stream=5)
+    y_ref = F.layer_norm(x, (D,), w, b)
+    y_ref.backward(dy)
+    f = lambda *s: torch.empty(s, device="cuda")
+    y, mean, rstd = f(M, D), f(M), f(M)
+    xd = x.detach().cuda()
+    ops.layernorm_fwd(xd, w.detach().cuda(), b.detach().cuda(), y, mean, rstd, M, D)
+    assert_close(y, y_ref.detach(), atol=1e-5, rtol=1e-5, name="LN fwd")
+    dx, dw, db = f(M, D), f(D), f(D)
+    ops.layernorm_bwd(dy.cuda(), xd, w.detach().cuda(), mean, rstd, dx, dw, db, f(ops.colreduce_ws_elems(M, D)), M, D, add=add.cuda())
+    assert_close(dx, x.grad + add, atol=1e-5, rtol=1e-5, name="LN dx (+add)")
+    assert_close(dw, w.grad, atol=1e-4, rtol=2e-5, name="LN dw")
+    assert_close(db, b.grad, atol=1e-4, rtol=2e-5, name="LN db")
+    d2 = dy.cuda().clone()                                                         # in place
+    ops.layernorm_bwd(d2, xd, w.detach().cuda(), mean, rstd, d2, dw, db, f(ops.colreduce_ws_elems(M, D)), M, D)
+    assert_close(d2, x.grad, atol=1e-5, rtol=1e-5, name="LN dx in place")
+
+
+@pytest.mark.parametrize("B,H,n,hd", [(2, 12, 257, 64), (3, 4, 50, 64), (1, 2, 130, 32)])
+def test_attention_pieces(ops, B, H, n, hd):
+    """The six strided batched GEMMs + masked softmax of Attention.forward / backward (m3ae.py:102-125) vs autograd."""
+    D = H * hd
+    qkv = O.portable_normal(n, (B, n, 3 * D), stream=1, std=0.7).requires_grad_(True)
+    pm = torch.zeros(B, n)
+    for b in range(B):
+        pm[b, n - 7 * (b + 1):] = 1.0
+    dO = O.portable_normal(n, (B, n, D), stream=2)
+    q4 = qkv.view(B, n, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = torch.matmul(q4[0], q4[1].transpose(-2, -1)) * hd ** -0.5
+    att = torch.where(pm[:, None, None, :].expand(att.shape) > 0, torch.tensor(-1e7), att)
+    P_ref = F.softmax(att, dim=-1)
+    o_ref = torch.matmul(P_ref, q4[2]).permute(0, 2, 1, 3).reshape(B, n, D)
+    o_ref.backward(dO)
+    qd = qkv.detach().cuda().view(B * n, 3 * D)
+    f = lambda *s: torch.empty(s, device="cuda")
+    P, o = f(B, H, n, n), f(B * n, D)
+    qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
+    ops.bgemm(qd, qd, P, B, H, n, n, hd, qs, (n * 3 * D, hd, 1, 3 * D), ss, hd ** -0.5, b_off=D)
+    ops.softmax_fwd(P, pm.cuda(), B, H, n)
+    assert_close(P, P_ref.detach(), atol=2e-6, rtol=1e-5, name="softmax(QK^T)")
+    ops.bgemm(P, qd, o, B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), os_, 1.0, b_off=2 * D)
+    assert_close(o.view(B, n, D), o_ref.detach(), atol=0, rtol=2e-5, name="PV")
+    dP, dqkv = f(B, H, n, n), torch.zeros((B * n, 3 * D), device="cuda")
+    dOd = dO.cuda().view(B * n, D)
+    ops.bgemm(dOd, qd, dP, B, H, n, n, hd, os_, (n * 3 * D, hd, 1, 3 * D), ss, 1.0, b_off=2 * D)
+    ops.bgemm(P, dOd, dqkv, B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * D, hd, D, 1), qs, 1.0, c_off=2 * D)
+    ops.softmax_bwd(P, dP, B, H, n)
+    ops.bgemm(dP, qd, dqkv, B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), qs, hd ** -0.5, b_off=D)
+    ops.bgemm(dP, qd, dqkv, B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * 3 * D, hd, 3 * D, 1), qs, hd ** -0.5, c_off=D)
+    assert_close(dqkv.view(B, n, 3 * D), qkv.grad, atol=1e-7, rtol=3e-5, name="d qkv")
+
+
+def test_assemble_patchify_avgpool(ops):
+    B, L, D, V = 3, 256, 768, 500
+    table = O.portable_normal(1, (V, D), stream=1)
+    ids = torch.from_numpy((O.portable_uniform(2, B * L, 3) * V).astype(np.int64)).view(B, L)
+    ids[0, :5] = 7                                                                  # duplicates -> scatter-add collisions
+    pos, typ, cls = O.sincos_pos_embed_1d(D, L), O.portable_normal(3, (D,), stream=2), O.portable_normal(3, (D,), stream=3)
+    want = torch.cat([cls.expand(B, 1, D), F.embedding(ids, table) + pos[None] + typ], dim=1)
+    x0 = torch.empty((B, L + 1, D), device="cuda")
+    ops.tokens_assemble(x0, table.cuda(), ids.cuda(), pos.cuda(), typ.cuda(), cls.cuda(), B, L, D)
+    assert_close(x0, want, atol=1e-6, name="assemble (text)")
+    lin = O.portable_normal(4, (B, L, D), stream=1)
+    x1 = torch.zeros((B, L + 1, D), device="cuda")
+    x1[:, 1:] = lin.cuda()
+    pos2 = O.sincos_pos_embed_2d(D, L)
+    ops.tokens_assemble(x1, None, None, pos2.cuda(), typ.cuda(), cls.cuda(), B, L, D)
+    assert_close(x1, torch.cat([cls.expand(B, 1, D), lin + pos2[None] + typ], dim=1), atol=1e-6, name="assemble (image)")
+    from mla_hip.m3ae import sincos_pos_embed
+    assert torch.equal(sincos_pos_embed(D, L, True), pos2) and torch.equal(sincos_pos_embed(D, L, False), pos)
+    # backward
+    dx0 = O.portable_normal(5, (B, L + 1, D), stream=1)
+    tot = torch.empty(D, device="cuda")
+    ops.colsum_rows(dx0.cuda().view(-1, D), tot, torch.empty(ops.colreduce_ws_elems(B * (L + 1), D), device="cuda"), B * (L + 1), D)
+    dcls, dtyp, dtab = torch.empty(D, device="cuda"), torch.empty(D, device="cuda"), torch.zeros((V, D), device="cuda")
+    ops.tokens_assemble_bwd(dx0.cuda(), tot, ids.cuda(), dcls, dtyp, dtab, B, L, D)
+    assert_close(dcls, dx0[:, 0].sum(0), atol=1e-5, name="dcls")
+    assert_close(dtyp, dx0[:, 1:].sum((0, 1)), atol=2e-4, name="dtype")
+    ref_tab = torch.zeros(V, D).index_add_(0, ids.reshape(-1), dx0[:, 1:].reshape(-1, D))
+    assert_close(dtab, ref_tab, atol=1e-5, name="embedding scatter-add")
+    # patchify == einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)'
+    img = O.portable_normal(6, (2, 3, 64, 48), stream=1)
+    out = torch.empty((2 * 4 * 3, 768), device="cuda")
+    ops.patchify(img.cuda(), out, 16)
+    assert torch.equal(out.cpu().view(2, 12, 768), O.patchify(img))
+    # token mean at C = 768
+    y = O.portable_normal(7, (B, 257, 768), stream=1)
+    feat = torch.empty((B, 768), device="cuda")
+    ops.avgpool_fwd(y.cuda(), feat, B, 257, 768)
+    assert_close(feat, y.mean(1), atol=1e-6, name="token mean")
+
+
+def _load(model, pa, pv, hd):
+    sd = {f"mae_a.{k}": v for k, v in pa.items()}
+    sd.update({f"mae_v.{k}": v for k, v in pv.items()})
+    sd.update({f"fusion_module.fc_out.{k}": v for k, v in hd.items()})
+    model.load_state_dict(sd)
+
+
+class _Args:
+    fusion_method, dataset, gs_flag, modulation = "concat", "Food101", True, "Normal"
+
+
+def test_m3ae_step_vs_reference_golden(golden_dir):
+    from mla_hip import M3AEClassifier, MLATrainer
+    import mla_hip.model as mm
+    fx = np.load(os.path.join(golden_dir, "m3ae_small.npz"))
+    B, depth, vocab, C, steps, seed = [int(v) for v in fx["meta"]]
+    mm.N_CLASSES["Food101"] = C                                   # the fixture uses a small class count (fixture size)
+    try:
+        model = M3AEClassifier(_Args(), depth=depth, text_vocab_size=vocab, seed=0)
+    finally:
+        mm.N_CLASSES["Food101"] = 101
+    pa, pv = O.make_m3ae_params(seed, depth=depth, vocab=vocab), O.make_m3ae_params(seed + 1, depth=depth, vocab=vocab)
+    _load(model, pa, pv, O.make_head_params(768, C, seed + 2))
+    tr = MLATrainer(model)
+    tr.keep_debug = True
+    for s in range(steps):
+        token = torch.from_numpy(np.minimum((O.portable_uniform(seed + 50 + s, B * 256, 7) * vocab).astype(np.int64), vocab - 1)).view(B, 1, 256)
+        pm = torch.zeros(B, 1, 256)
+        for b in range(B):
+            pm[b, 0, 40 + 37 * b:] = 1.0
+        image = O.portable_normal(seed + 50 + s, (B, 3, 256, 256), stream=3)
+        label = O.portable_labels(seed + 50 + s, B, C)
+        losses = tr.train_step(token.cuda(), pm.cuda(), image.cuda(), label.cuda(), s, 10)
+        torch.cuda.synchronize()
+        tol = 2e-4 if s == 0 else 1e-3                            # step 1 is free-running (see test_step_gpu.py)
+        assert_close(tr.last["a"], fx[f"s{s}.feat_a"], atol=tol, name=f"s{s} feat_a")
+        assert_close(tr.last["v"], fx[f"s{s}.feat_v"], atol=tol, name=f"s{s} feat_v")
+        for k in ("out_a", "out_v"):
+            assert_close(tr.last[k], fx[f"s{s}.{k}"], atol=tol, name=f"s{s} {k}")
+        for k in ("loss_a", "loss_v"):
+            assert_close(losses[k].reshape(()), fx[f"s{s}.{k}"], atol=tol, name=f"s{s} {k}")
+        assert_close(tr.last["head_grad_a_raw"], fx[f"s{s}.head_grad_a_raw"], atol=tol, name="raw head grad a")
+        assert_close(tr.last["head_grad_v_raw"], fx[f"s{s}.head_grad_v_raw"], atol=tol, name="raw head grad v")
+        # Projected head gradient.  On mixed-sign transformer features the reference's element-wise denominator
+        # alpha + k_i r_j (utils/utils.py:36, Q2) nearly vanishes (min 1.1e-6 here): measured on this fixture the CPU
+        # fp32 evaluation is 6e-4 from an fp64 evaluation at step 0, a 1e-6 relative feature perturbation moves it by
+        # 1.7e-3, and from step 1 on (projector collapsed onto a few entries) fp32 results are noise-dominated.  So:
+        #   step 0: fixture within 3e-3 absolute;
+        #   every firing: the HIP result must be as close to an fp64 evaluation of ITS OWN inputs as the reference's
+        #   fp32 arithmetic (CPU torch on the same inputs) is, with a x20 margin.
+        if s == 0:
+            assert_close(tr.last["head_grad_v"], fx["s0.head_grad_v"], atol=3e-3, name="projected head grad v (step 0)")
+        for nm in ("a", "v"):
+            fired = not (s == 0 and nm == "a")                      # first call is skipped (Q5)
+            feat, G0, Pl0 = tr.last[nm].cpu(), tr.last[f"head_grad_{nm}_raw"].cpu(), tr.last[f"Pl_before_{nm}"].cpu()
+            if not fired:
+                assert torch.equal(tr.last[f"head_grad_{nm}"].cpu(), G0)
+                continue
+            exp = 2 * s + (0 if nm == "a" else 1)
+            _, g32 = O.gs_before_update(Pl0, feat, G0, s, 10, exp, "as_intended")
+            _, g64 = O.gs_before_update(Pl0.double(), feat.double(), G0.double(), s, 10, exp, "as_intended")
+            err_ref = (g32.double() - g64).abs().max().item()
+            err_hip = (tr.last[f"head_grad_{nm}"].cpu().double() - g64).abs().max().item()
+            assert err_hip <= 20 * err_ref + 1e-4, f"s{s} projection {nm}: HIP {err_hip:.3e} vs reference-arithmetic {err_ref:.3e}"
+        for nm, enc in (("a", model.mae_a), ("v", model.mae_v)):
+            got = enc.grads_as_reference()
+            for key in fx.files:
+                if key.startswith(f"s{s}.grad.{nm}.") and key.endswith(".abssum"):
+                    pname = key[len(f"s{s}.grad.{nm}."):-len(".abssum")]
+                    want = float(fx[key])
+                    have = got[pname].double().abs().sum().item()
+                    assert abs(have - want) <= (1e-3 if s == 0 else 2e-2) * want + 1e-9, (key, have, want)
+        sd = model.state_dict()
+        assert_close(sd["mae_a.cls_token"], fx[f"s{s}.text.cls_token"], atol=1e-5, name="text cls_token after SGD")
+        assert_close(sd["mae_v.cls_token"], fx[f"s{s}.image.cls_token"], atol=1e-5, name="image cls_token after SGD")
+        assert_close(sd[f"mae_v.encoder.blocks.{depth - 1}.transformer_mlp.fc2.weight"].flatten()[:64], fx[f"s{s}.image.fc2w.head"],
+                     atol=1e-6, name="fc2 weight slice after SGD")
+    assert tr.gs_plugin.exp_count == 2 * steps
+
+
+@pytest.mark.parametrize("depth,B", [(2, 2), (12, 2)])
+def test_m3ae_encoder_grads_vs_oracle(depth, B):
+    """Every parameter gradient of both modality encoders vs the autograd oracle (full depth 12 included)."""
+    from mla_hip import M3AEEncoder
+    vocab, seed = 300, 77
+    for kind in ("text", "image"):
+        p = O.make_m3ae_params(seed, depth=depth, vocab=vocab)
+        enc = M3AEEncoder(kind, depth=depth, text_vocab_size=vocab, seed=0)
+        enc.load_state_dict(p)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        dfeat = O.portable_normal(seed, (B, 768), stream=9)
+        if kind == "text":
+            tok = torch.from_numpy((O.portable_uniform(seed, B * 256, 5) * vocab).astype(np.int64)).view(B, 1, 256)
+            pm = torch.zeros(B, 1, 256)
+            pm[0, 0, 100:] = 1.0
+            feat_ref = O.m3ae_feature(leaves, token=tok, padding_mask=pm)
+            feat = enc.forward(tok.cuda(), pm.cuda())
+        else:
+            img = O.portable_normal(seed, (B, 3, 256, 256), stream=4)
+            feat_ref = O.m3ae_feature(leaves, image=img)
+            feat = enc.forward(img.cuda())
+        assert_close(feat, feat_ref.detach(), atol=2e-5, rtol=2e-5, name=f"{kind} feature")
+        feat_ref.backward(dfeat)
+        enc.backward_from_pooled(dfeat.cuda())
+        torch.cuda.synchronize()
+        got = enc.grads_as_reference()
+        used = {k for k, v in leaves.items() if v.grad is not None}
+        assert used == set(got), "parameters that receive a gradient must match the reference's"
+        for k in used:
+            err = rel_l2(got[k], leaves[k].grad)
+            assert err < 1e-4, (kind, k, err)
