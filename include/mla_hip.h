@@ -146,15 +146,18 @@ int mla_softmax_fwd(float* S, const float* pad_mask, int B, int H, int n, void* 
 /* dS = P * (dP - rowsum(dP*P)), in place in dP. */
 int mla_softmax_bwd(const float* P, float* dP, int B, int H, int n, void* stream);
 /* forward_representation token assembly (m3ae.py:342-366): x0[b][0] = cls; x0[b][1+i] = (table[ids[b][i]] if
- * table else x0[b][1+i]) + pos[i] + type.  x0 is (B, L+1, D). */
+ * table else x0[b][1+i]) + pos[i] + type.  x0 is (B, L+1, D).  cls == NULL (CAV-MAE, cav_mae.py:341-343): no
+ * [cls] row, x0 is (B, L, D) and x0[b][i] += pos[i] + type. */
 int mla_tokens_assemble(float* x0, const float* table, const int64_t* ids, const float* pos, const float* type,
                         const float* cls, int B, int L, int D, void* stream);
 /* its gradients: dcls, dtype (needs colsum_all = column sum of dx0 over all B*(L+1) rows) and, for text,
  * dtable[ids] += dx0 rows (float atomics; dtable pre-zeroed). */
 int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls, float* dtype,
                             float* dtable, int B, int L, int D, void* stream);
-/* einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)' (basic_model.py:184-186) */
-int mla_patchify(const float* img, float* out, int B, int C, int H, int W, int P, void* stream);
+/* einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)' (basic_model.py:184-186); also the im2col of CAV-MAE's
+ * conv16x16/16 PatchEmbed (cav_mae.py:69-84).  transposed != 0: img is stored (B,C,W,H) (spectrogram (B,time,freq)
+ * viewed as (B,1,freq,time), cav_mae.py:339-340). */
+int mla_patchify(const float* img, float* out, int B, int C, int H, int W, int P, int transposed, void* stream);
 
 /* ---- torch.optim.SGD(momentum, weight_decay) (main.py:749, 439, 451) ------------------------- */
 /* d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf.  g == NULL means zero gradient

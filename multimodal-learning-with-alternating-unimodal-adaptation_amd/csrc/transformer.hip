@@ -337,12 +337,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(float* __restrict__ x0, c
                                                         const float* __restrict__ type, const float* __restrict__ cls,
                                                         int B, int L, int D) {
   const int d4n = D >> 2;
-  const size_t total = (size_t)B * (L + 1) * d4n;
+  const int hc = cls ? 1 : 0;                       // CAV-MAE has no [cls] token (cav_mae.py:337-343)
+  const size_t total = (size_t)B * (L + hc) * d4n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % d4n);
     const size_t r = i / d4n;
-    const int t = (int)(r % (L + 1));
-    const size_t b = r / (L + 1);
+    const int t = (int)(r % (L + hc)) + (1 - hc);   // t == 0 only for the cls row
+    const size_t b = r / (L + hc);
     f32x4 v;
     if (t == 0) {
       v = reinterpret_cast<const f32x4*>(cls)[c];
@@ -365,8 +366,10 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
   if (gid < (size_t)D) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dx0[(size_t)b * (L + 1) * D + gid];
-    dcls[gid] = s;
+    if (dcls) {
+      for (int b = 0; b < B; ++b) s += dx0[(size_t)b * (L + 1) * D + gid];
+      dcls[gid] = s;
+    }
     dtype[gid] = tot[gid] - s;
   }
   if (dtable) {
@@ -382,8 +385,9 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
 
 extern "C" int mla_tokens_assemble(float* x0, const float* table, const int64_t* ids, const float* pos, const float* type,
                                    const float* cls, int B, int L, int D, void* stream) {
-  MLA_REQUIRE(x0 && pos && type && cls && B > 0 && L > 0 && D % 4 == 0 && ((table == nullptr) == (ids == nullptr)),
+  MLA_REQUIRE(x0 && pos && type && B > 0 && L > 0 && D % 4 == 0 && ((table == nullptr) == (ids == nullptr)),
               "mla_tokens_assemble: bad argument");
+  MLA_REQUIRE(cls || !table, "mla_tokens_assemble: the text path always has a [cls] token");
   size_t blocks = ((size_t)B * (L + 1) * (D / 4) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   assemble_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x0, table, ids, pos, type, cls, B, L, D);
@@ -393,8 +397,9 @@ extern "C" int mla_tokens_assemble(float* x0, const float* table, const int64_t*
 
 extern "C" int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls,
                                        float* dtype, float* dtable, int B, int L, int D, void* stream) {
-  MLA_REQUIRE(dx0 && colsum_all && dcls && dtype && B > 0 && L > 0 && D > 0 && ((dtable == nullptr) == (ids == nullptr)),
+  MLA_REQUIRE(dx0 && colsum_all && dtype && B > 0 && L > 0 && D > 0 && ((dtable == nullptr) == (ids == nullptr)),
               "mla_tokens_assemble_bwd: bad argument");
+  MLA_REQUIRE(dcls || !dtable, "mla_tokens_assemble_bwd: the text path always has a [cls] token");
   size_t blocks = dtable ? ((size_t)B * L * D + 255) / 256 : (size_t)cdiv(D, 256);
   if (blocks > 16384) blocks = 16384;
   if (blocks < (size_t)cdiv(D, 256)) blocks = cdiv(D, 256);
@@ -404,8 +409,10 @@ extern "C" int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all
 }
 
 // einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)': out[b][h*GW+w][c*P*P + p1*P + p2] = img[b][c][h*P+p1][w*P+p2]
+// transposed != 0: the image is stored (B, C, W, H) -- the spectrogram (B, time, freq) that cav_mae.py:339-340 views as
+// (B, 1, freq, time) by unsqueeze + transpose, folded into the gather instead of a transposed copy.
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int C,
-                                                        int Himg, int Wimg, int P) {
+                                                        int Himg, int Wimg, int P, int transposed) {
   const int GW = Wimg / P, GH = Himg / P, F = C * P * P;
   const size_t total = (size_t)B * GH * GW * F;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -415,15 +422,16 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int h = (int)(r % GH);
     const size_t b = r / GH;
     const int p2 = f % P, p1 = (f / P) % P, c = f / (P * P);
-    out[i] = img[((b * C + c) * Himg + h * P + p1) * Wimg + w * P + p2];
+    const int y = h * P + p1, x = w * P + p2;
+    out[i] = transposed ? img[((b * C + c) * Wimg + x) * Himg + y] : img[((b * C + c) * Himg + y) * Wimg + x];
   }
 }
 
-extern "C" int mla_patchify(const float* img, float* out, int B, int C, int H, int W, int P, void* stream) {
+extern "C" int mla_patchify(const float* img, float* out, int B, int C, int H, int W, int P, int transposed, void* stream) {
   MLA_REQUIRE(img && out && B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0, "mla_patchify: bad argument");
   size_t blocks = ((size_t)B * C * H * W + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  patchify_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(img, out, B, C, H, W, P);
+  patchify_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(img, out, B, C, H, W, P, transposed);
   MLA_CHECK_LAUNCH("patchify_kernel");
   return MLA_OK;
 }

@@ -7,7 +7,7 @@ from ._lib import MLAHipError, LIB_PATH  # noqa: F401
 from .dist import Comm  # noqa: F401
 from .encoder import ResNet18Encoder  # noqa: F401
 from .model import AVClassifier, ConcatFusion, SharedHead  # noqa: F401
-from .m3ae import M3AEClassifier, M3AEEncoder  # noqa: F401
+from .m3ae import ConcatFusion3, M3AEClassifier, M3AEEncoder, Modal3Classifier  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .plugin import GSPlugin  # noqa: F401
 from .trainer import MLATrainer  # noqa: F401

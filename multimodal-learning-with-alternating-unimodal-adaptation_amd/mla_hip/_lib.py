@@ -60,7 +60,7 @@ PROTOTYPES = {
     "mla_softmax_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mla_tokens_assemble": (_I, [_P] * 6 + [_I, _I, _I, _P]),
     "mla_tokens_assemble_bwd": (_I, [_P] * 6 + [_I, _I, _I, _P]),
-    "mla_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mla_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

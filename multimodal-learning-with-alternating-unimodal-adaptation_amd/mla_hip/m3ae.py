@@ -1,5 +1,6 @@
-"""M3AE modality encoder on the HIP kernels (reference: models/m3ae.py:48-179, 300-370;
-models/basic_model.py:127-200 M3AEClassifier).
+"""Transformer modality encoders on the HIP kernels: M3AE text / image (reference: models/m3ae.py:48-179,
+300-370; models/basic_model.py:127-200 M3AEClassifier) and the CAV-MAE audio branch (models/cav_mae.py:69-113,
+116-186, 337-351; models/basic_model.py:202-275 Modal3Classifier).
 
 One `M3AEEncoder` per modality, like the reference's `mae_a` (text) / `mae_v` (image): pre-LN ViT-B
 (emb 768, 12 heads, mlp x4) over [cls] + 256 tokens, token-mean feature.  DropPath == identity (SURVEY Q10:
@@ -51,19 +52,26 @@ class M3AEEncoder:
 
     def __init__(self, kind: str, device="cuda", depth: int = 12, emb_dim: int = 768, num_heads: int = 12,
                  text_vocab_size: int = 30522, patch_dim: int = 768, seed: Optional[int] = None):
-        if kind not in ("text", "image"):
-            raise ValueError("kind must be 'text' or 'image'")
+        if kind not in ("text", "image", "audio"):
+            raise ValueError("kind must be 'text', 'image' or 'audio'")
         self.kind, self.device = kind, torch.device(device)
+        if kind == "audio":
+            patch_dim = 256                  # conv 16x16 over 1 channel (cav_mae.py:127)
+        self.has_cls = kind != "audio"       # CAV-MAE has no [cls] token
+        self.audio_tokens = 512              # audio_length * 128 / 256 (cav_mae.py:131)
         self.depth, self.D, self.H, self.V, self.PD = depth, emb_dim, num_heads, text_vocab_size, patch_dim
         D = emb_dim
         dims = {"D": (D,), "3D": (3 * D,), "4D": (4 * D,), "D,3D": (D, 3 * D), "D,D": (D, D), "D,4D": (D, 4 * D), "4D,D": (4 * D, D)}
         # ---- flat layout of the parameters this modality trains (Linear weights as [in][out])
         lay: List[Tuple[str, Tuple[int, ...]]] = []
         if kind == "text":
-            lay += [("text_embedding.weight", (text_vocab_size, D)), ("encoder_text_type_embedding", (D,))]
-        else:
-            lay += [("image_embedding.weight", (patch_dim, D)), ("image_embedding.bias", (D,)), ("encoder_image_type_embedding", (D,))]
-        lay.append(("cls_token", (D,)))
+            lay += [("text_embedding.weight", (text_vocab_size, D)), ("encoder_text_type_embedding", (D,)), ("cls_token", (D,))]
+        elif kind == "image":
+            lay += [("image_embedding.weight", (patch_dim, D)), ("image_embedding.bias", (D,)), ("encoder_image_type_embedding", (D,)),
+                    ("cls_token", (D,))]
+        else:   # CAV-MAE audio: conv patch embed (as [256][D]), modality embedding, LEARNED position embedding (tr_pos=True)
+            lay += [("patch_embed_a.proj.weight", (patch_dim, D)), ("patch_embed_a.proj.bias", (D,)), ("modality_a", (D,)),
+                    ("pos_embed_a", (self.audio_tokens, D))]
         for i in range(depth):
             lay += [(f"encoder.blocks.{i}.{n}", dims[s]) for n, s in self.BLOCK_PARAMS]
         lay += [("encoder.layer_norm.weight", (D,)), ("encoder.layer_norm.bias", (D,))]
@@ -82,9 +90,11 @@ class M3AEEncoder:
         if kind == "text":
             self.unused = {"image_embedding.weight": torch.zeros((patch_dim, D), **f32), "image_embedding.bias": torch.zeros(D, **f32),
                            "encoder_image_type_embedding": torch.zeros(D, **f32)}
-        else:
+        elif kind == "image":
             self.unused = {"text_embedding.weight": torch.zeros((text_vocab_size, D), **f32),
                            "encoder_text_type_embedding": torch.zeros(D, **f32)}
+        else:
+            self.unused = {}     # CAVMAEFT's visual branch / unused norms are not materialised (never touched by forward_feat(.,'a'))
         self._pos: Dict[int, torch.Tensor] = {}
         self._ws: dict = {}
         self._key = None
@@ -101,6 +111,10 @@ class M3AEEncoder:
                 t.copy_(torch.randn(shp, generator=gen))                                   # normal_(0, 1)
             elif name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding"):
                 t.copy_(torch.randn(shp, generator=gen) + 0.02)                            # torch.empty().normal_(0.02): mean .02, std 1
+            elif name == "modality_a":
+                t.copy_(torch.randn(shp, generator=gen) * 0.02)                            # cav_mae.py:171
+            elif name == "pos_embed_a":
+                t.copy_(self._cav_pos_embed())                                             # cav_mae.py:160-161 (sin-cos init, then trained)
             elif "layer_norm" in name:
                 t.fill_(1.0 if name.endswith("weight") else 0.0)
             elif len(shp) == 2:
@@ -110,11 +124,50 @@ class M3AEEncoder:
                 fan_in = 4 * self.D if name.endswith("fc2.bias") else (self.PD if name == "image_embedding.bias" else self.D)
                 t.copy_((torch.rand(shp, generator=gen) * 2 - 1) / math.sqrt(fan_in))
 
+    def _cav_pos_embed(self) -> torch.Tensor:
+        """get_2d_sincos_pos_embed(D, 8, L/8) of cav_mae.py:47-66 (grid 8 x L/8, 'w goes first')."""
+        D, L = self.D, self.audio_tokens
+        gh, gw = 8, L // 8
+        grid = np.stack(np.meshgrid(np.arange(gw, dtype=np.float32), np.arange(gh, dtype=np.float32)), axis=0).reshape([2, 1, gw, gh])
+        emb = np.concatenate([_sincos_1d(D // 2, grid[0]), _sincos_1d(D // 2, grid[1])], axis=1)
+        return torch.from_numpy(emb.astype(np.float32))
+
+    def _ref_name(self, name: str) -> str:
+        """internal (M3AE-style) parameter name -> reference state_dict key."""
+        if self.kind != "audio" or not name.startswith("encoder."):
+            return name
+        if name.startswith("encoder.layer_norm."):
+            return name.replace("encoder.layer_norm.", "norm_a.")                          # cav_mae.py:145, 349
+        _e, _b, i, rest = name.split(".", 3)
+        i = int(i)
+        shared = i >= self.depth - 1                                                       # 11 blocks_a + 1 blocks_u (cav_mae.py:141-143)
+        pre = f"blocks_u.{i - (self.depth - 1)}." if shared else f"blocks_a.{i}."
+        sub = {"layer_norm1": "norm1_a" if shared else "norm1", "layer_norm2": "norm2_a" if shared else "norm2",
+               "attention.qkv_linear": "attn.qkv", "attention.fc": "attn.proj", "transformer_mlp.fc1": "mlp.fc1",
+               "transformer_mlp.fc2": "mlp.fc2"}
+        for k, v in sub.items():
+            if rest.startswith(k + "."):
+                return pre + v + rest[len(k):]
+        raise KeyError(name)
+
     def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
         """Reference keys and layouts (nn.Linear.weight is (out, in); type embeddings / cls are (1,1,D))."""
         sd = {}
         for name in self.layout:
             t = self.p[name]
+            if self.kind == "audio":
+                key = prefix + self._ref_name(name)
+                if name == "patch_embed_a.proj.weight":
+                    sd[key] = t.t().contiguous().view(self.D, 1, 16, 16)                   # Conv2d(1, D, 16, 16) weight
+                elif name == "modality_a":
+                    sd[key] = t.clone().view(1, 1, -1)
+                elif name == "pos_embed_a":
+                    sd[key] = t.clone().view(1, *t.shape)
+                elif t.dim() == 2:
+                    sd[key] = t.t().contiguous()
+                else:
+                    sd[key] = t.clone()
+                continue
             if name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding"):
                 sd[prefix + name] = t.clone().view(1, 1, -1)
             elif t.dim() == 2 and name != "text_embedding.weight":
@@ -132,13 +185,18 @@ class M3AEEncoder:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
         for name in list(self.layout) + list(self.unused):
-            if prefix + name not in sd:
+            key = prefix + self._ref_name(name)
+            if key not in sd:
                 if strict:
-                    raise KeyError(f"missing key {prefix + name}")
+                    raise KeyError(f"missing key {key}")
                 continue
-            src = sd[prefix + name].to(self.device, torch.float32)
+            src = sd[key].to(self.device, torch.float32)
             dst = self.p[name] if name in self.layout else self.unused[name]
-            if src.dim() == 3:
+            if name == "patch_embed_a.proj.weight":
+                src = src.reshape(self.D, -1).t()
+            elif name == "pos_embed_a":
+                src = src.reshape(dst.shape)
+            elif src.dim() == 3:
                 src = src.reshape(-1)
             elif src.dim() == 2 and name != "text_embedding.weight":
                 src = src.t()
@@ -148,6 +206,17 @@ class M3AEEncoder:
         out = {}
         for name in self.layout:
             t = self.g[name]
+            if self.kind == "audio":
+                key = self._ref_name(name)
+                if name == "patch_embed_a.proj.weight":
+                    out[key] = t.t().contiguous().view(self.D, 1, 16, 16)
+                elif name == "modality_a":
+                    out[key] = t.clone().view(1, 1, -1)
+                elif name == "pos_embed_a":
+                    out[key] = t.clone().view(1, *t.shape)
+                else:
+                    out[key] = t.t().contiguous() if t.dim() == 2 else t.clone()
+                continue
             if name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding"):
                 out[name] = t.clone().view(1, 1, -1)
             elif t.dim() == 2 and name != "text_embedding.weight":
@@ -160,7 +229,7 @@ class M3AEEncoder:
     def _plan(self, B: int, L: int) -> dict:
         if self._key == (B, L):
             return self._ws
-        D, H, n = self.D, self.H, L + 1
+        D, H, n = self.D, self.H, L + (1 if self.has_cls else 0)
         M = B * n
         f32 = dict(device=self.device, dtype=torch.float32)
         ws: dict = {"B": B, "L": L, "n": n, "M": M}
@@ -176,9 +245,10 @@ class M3AEEncoder:
         ws["y"] = torch.empty((M, D), **f32)
         ws["stf"] = torch.empty((2, M), **f32)
         ws["feat"] = torch.empty((B, D), **f32)
-        if self.kind == "image":
+        if self.kind != "text":
             ws["patches"] = torch.empty((B * L, self.PD), **f32)
-        ws["pos"] = sincos_pos_embed(D, L, two_d=(self.kind == "image")).to(self.device)
+        if self.kind != "audio":
+            ws["pos"] = sincos_pos_embed(D, L, two_d=(self.kind == "image")).to(self.device)
         self._ws, self._key = ws, (B, L)
         return ws
 
@@ -214,6 +284,18 @@ class M3AEEncoder:
             ws["pm"] = torch.cat([torch.zeros((B, 1), device=self.device), pm], dim=1).contiguous()   # cls is never masked (m3ae.py:347)
             ops.tokens_assemble(ws["x0"], self.p["text_embedding.weight"], ids, ws["pos"], self.p["encoder_text_type_embedding"],
                                 self.p["cls_token"], B, L, D, stream=st)
+        elif self.kind == "audio":
+            # cav_mae.py:337-343: (B, time, freq) -> unsqueeze, transpose -> conv16x16/16 -> (B, 8*64, D) + pos + modality
+            B, T_, F_ = inp.shape
+            L = (F_ // 16) * (T_ // 16)
+            if L != self.audio_tokens:
+                raise MLAHipError(f"audio encoder expects {self.audio_tokens} patches, got {L}")
+            ws = self._plan(B, L)
+            ws["pm"] = None
+            ops.patchify(inp.contiguous().float(), ws["patches"], 16, transposed_hw=(F_, T_), stream=st)
+            ops.linear_fwd(ws["patches"], self.p["patch_embed_a.proj.weight"], self.p["patch_embed_a.proj.bias"], ws["x0"], 1, B * L,
+                           self.PD, D, stream=st)
+            ops.tokens_assemble(ws["x0"], None, None, self.p["pos_embed_a"], self.p["modality_a"], None, B, L, D, stream=st)
         else:
             B = inp.shape[0]
             L = (inp.shape[2] // 16) * (inp.shape[3] // 16)
@@ -297,7 +379,16 @@ class M3AEEncoder:
             ws["dA"], ws["dC"] = dx, dC
         # ---- token assembly (m3ae.py:342-366)
         ops.colsum_rows(dx, ws["colsum"], red, M, D, stream=st)
-        if self.kind == "text":
+        if self.kind == "audio":
+            # x0 = conv(patches) + pos_embed_a + modality_a: d modality = d conv-bias = sum over all tokens,
+            # d pos[i] = sum over the batch, d conv-weight = patches^T dx
+            self.g["modality_a"].copy_(ws["colsum"])
+            self.g["patch_embed_a.proj.bias"].copy_(ws["colsum"])
+            if "red_pos" not in ws:
+                ws["red_pos"] = torch.empty(ops.colreduce_ws_elems(B, L * D), device=self.device, dtype=torch.float32)
+            ops.colsum_rows(dx, self.g["pos_embed_a"], ws["red_pos"], B, L * D, stream=st)
+            ops.linear_wgrad(ws["patches"], dx, self.g["patch_embed_a.proj.weight"], wgw, 1, B * L, self.PD, D, stream=st)
+        elif self.kind == "text":
             self.g["text_embedding.weight"].zero_()
             ops.tokens_assemble_bwd(dx, ws["colsum"], ws["ids"], self.g["cls_token"], self.g["encoder_text_type_embedding"],
                                     self.g["text_embedding.weight"], B, L, D, stream=st)
@@ -352,6 +443,66 @@ class M3AEClassifier:
             sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
         self.mae_a.load_state_dict(sd, "mae_a.", strict)
         self.mae_v.load_state_dict(sd, "mae_v.", strict)
+        if "fusion_module.fc_out.weight" in sd:
+            self.fusion_module.fc_out.load_state_dict(sd, "fusion_module.fc_out.")
+        elif strict:
+            raise KeyError("missing key fusion_module.fc_out.weight")
+
+
+class ConcatFusion3:
+    """models/fusion_modules.py:26-35; under --gs_flag only `fc_out` is touched (main.py:432, 444, 456)."""
+
+    def __init__(self, input_dim: int = 768, output_dim: int = 4, device="cuda", seed: Optional[int] = None):
+        from .model import SharedHead
+        self.fc_out = SharedHead(input_dim, output_dim, device, seed)
+
+
+class Modal3Classifier:
+    """models/basic_model.py:202-275 under --gs_flag: CAV-MAE audio (mae_a) + M3AE image (mae_v) + M3AE text (mae_t),
+    shared head Linear(768 -> 4); MLA alternates a -> v -> t (main.py:432-466)."""
+
+    def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None):
+        from .model import N_CLASSES
+        fusion = getattr(args, "fusion_method", "concat")
+        dataset = getattr(args, "dataset", "IEMOCAP")
+        if dataset != "IEMOCAP":                                                    # basic_model.py:208-211
+            raise NotImplementedError("Incorrect dataset name {}".format(dataset))
+        if fusion != "concat":                                                      # basic_model.py:213-229
+            raise NotImplementedError("Incorrect fusion method: {}!".format(fusion))
+        if not getattr(args, "gs_flag", False):
+            raise NotImplementedError("mla_hip implements the --gs_flag (MLA) path only")
+        self.args, self.device = args, torch.device(device)
+        s = (lambda k: None if seed is None else seed + k)
+        self.fusion_module = ConcatFusion3(768, N_CLASSES[dataset], device, s(3))  # basic_model.py:218
+        self.mae_a = M3AEEncoder("audio", device, depth=depth, seed=s(0))                                     # :231 CAVMAEFT
+        self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1))   # :232
+        self.mae_t = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(2))    # :233
+        self.module = self
+
+    def mla_encoders(self):
+        return [("a", "audio", self.mae_a), ("v", "image", self.mae_v), ("t", "text", self.mae_t)]
+
+    def forward(self, token, padding_mask, visual, audio):
+        """a, v, t = model(token, padding_mask, image, spec)  (main.py:424; basic_model.py:252-275)."""
+        a = self.mae_a.forward(audio)
+        v = self.mae_v.forward(visual)
+        t = self.mae_t.forward(token, padding_mask)
+        return a, v, t
+
+    __call__ = forward
+
+    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
+        sd = {}
+        sd.update(self.fusion_module.fc_out.state_dict(prefix + "fusion_module.fc_out."))
+        for nm, enc in (("mae_a.", self.mae_a), ("mae_v.", self.mae_v), ("mae_t.", self.mae_t)):
+            sd.update(enc.state_dict(prefix + nm))
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        if any(k.startswith("module.") for k in sd):
+            sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        for nm, enc in (("mae_a.", self.mae_a), ("mae_v.", self.mae_v), ("mae_t.", self.mae_t)):
+            enc.load_state_dict(sd, nm, strict)
         if "fusion_module.fc_out.weight" in sd:
             self.fusion_module.fc_out.load_state_dict(sd, "fusion_module.fc_out.")
         elif strict:

@@ -312,6 +312,13 @@ def tokens_assemble_bwd(dx0, colsum_all, ids, dcls, dtype, dtable, B: int, L: in
                                               B, L, D, stream or cur_stream()), "mla_tokens_assemble_bwd")
 
 
-def patchify(img, out, P: int = 16, stream: Optional[int] = None):
-    B, C, H, W = img.shape
-    check(_lib.load().mla_patchify(_p(img), _p(out), B, C, H, W, P, stream or cur_stream()), "mla_patchify")
+def patchify(img, out, P: int = 16, transposed_hw: Optional[tuple] = None, stream: Optional[int] = None):
+    """img (B,C,H,W) -> out (B*(H/P)*(W/P), C*P*P).  transposed_hw=(H, W): img is stored (B, W, H) with C == 1."""
+    if transposed_hw is None:
+        B, C, H, W = img.shape
+        tr = 0
+    else:
+        B, C = img.shape[0], 1
+        H, W = transposed_hw
+        tr = 1
+    check(_lib.load().mla_patchify(_p(img), _p(out), B, C, H, W, P, tr, stream or cur_stream()), "mla_patchify")

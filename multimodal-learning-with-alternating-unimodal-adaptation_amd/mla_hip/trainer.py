@@ -76,8 +76,9 @@ class MLATrainer:
         self.gs_plugin.exp_count += 1                                                         # :442
 
     def train_step(self, *batch):
-        """AVClassifier:   train_step(spec, image, label, batch_step, len_dataloader)
-        M3AEClassifier: train_step(token, padding_mask, image, label, batch_step, len_dataloader)
+        """AVClassifier:     train_step(spec, image, label, batch_step, len_dataloader)
+        M3AEClassifier:   train_step(token, padding_mask, image, label, batch_step, len_dataloader)
+        Modal3Classifier: train_step(token, padding_mask, image, spec, label, batch_step, len_dataloader)
         spec (B,H,W) or (B,1,H,W); image (B,3,T,H,W) / (B,3,256,256); label int64 (B,).  Returns device scalars
         {'loss','loss_a','loss_v'} (no host sync; call .item() when needed, main.py:472-476)."""
         *inputs, label, batch_step, len_dataloader = batch

@@ -608,3 +608,108 @@ def mla_step_m3ae(st: M3AEState, token, padding_mask, image, label, batch_index:
     phase("v", st.image, lambda p: m3ae_feature(p, image=image, heads=heads))
     out["loss"] = out["loss_a"] * 0.55 + out["loss_v"] * 0.45
     return out
+
+
+# ======================================================================================
+# CAV-MAE audio branch: models/cav_mae.py:69-84 (PatchEmbed), 86-113 (Block with
+# modality-specific norms), 116-186 (CAVMAEFT.__init__), 337-351 (forward_feat(.., 'a')); models/basic_model.py
+# 252-275 (Modal3Classifier.forward).  PARITY UNPINNED: the Attention / Mlp arithmetic lives in timm==0.4.5
+# (requirements.txt:55; cav_mae.py:16, 93-94, 101), which is neither vendored nor installed, and the reference has
+# no test or fixture for this path.  Restated from timm 0.4.5's published definitions: Attention = qkv Linear
+# (bias) -> (B,N,3,H,hd) -> softmax(q k^T * hd^-0.5) v -> proj Linear; Mlp = fc1 -> GELU(erf) -> fc2.
+# ======================================================================================
+def cavmae_audio_param_names(depth: int = 12) -> List[str]:
+    names = ["patch_embed_a.proj.weight", "patch_embed_a.proj.bias", "modality_a", "pos_embed_a"]
+    for i in range(depth):
+        shared = i >= depth - 1
+        pre = f"blocks_u.{i - (depth - 1)}." if shared else f"blocks_a.{i}."
+        n1, n2 = ("norm1_a", "norm2_a") if shared else ("norm1", "norm2")
+        names += [pre + n1 + ".weight", pre + n1 + ".bias", pre + "attn.qkv.weight", pre + "attn.qkv.bias", pre + "attn.proj.weight",
+                  pre + "attn.proj.bias", pre + n2 + ".weight", pre + n2 + ".bias", pre + "mlp.fc1.weight", pre + "mlp.fc1.bias",
+                  pre + "mlp.fc2.weight", pre + "mlp.fc2.bias"]
+    return names + ["norm_a.weight", "norm_a.bias"]
+
+
+def make_cavmae_audio_params(seed: int, depth: int = 12, emb: int = 768, tokens: int = 512) -> Dict[str, torch.Tensor]:
+    p: Dict[str, torch.Tensor] = {}
+    for si, name in enumerate(cavmae_audio_param_names(depth)):
+        if name == "patch_embed_a.proj.weight":
+            shp, std = (emb, 1, 16, 16), (2.0 / (emb + 256)) ** 0.5
+        elif name == "pos_embed_a":
+            shp, std = (1, tokens, emb), 0.5
+        elif name == "modality_a":
+            shp, std = (1, 1, emb), 0.02
+        elif name.endswith("qkv.weight"):
+            shp, std = (3 * emb, emb), (2.0 / (4 * emb)) ** 0.5
+        elif name.endswith("qkv.bias"):
+            shp, std = (3 * emb,), 0.02
+        elif name.endswith("fc1.weight"):
+            shp, std = (4 * emb, emb), (2.0 / (5 * emb)) ** 0.5
+        elif name.endswith("fc1.bias"):
+            shp, std = (4 * emb,), 0.02
+        elif name.endswith("fc2.weight"):
+            shp, std = (emb, 4 * emb), (2.0 / (5 * emb)) ** 0.5
+        elif name.endswith("proj.weight"):
+            shp, std = (emb, emb), (1.0 / emb) ** 0.5
+        else:
+            shp, std = (emb,), 0.02
+        mean = 1.0 if ("norm" in name and name.endswith("weight")) else 0.0
+        p[name] = portable_normal(seed, shp, stream=3000 + si, mean=mean, std=0.05 if mean else std)
+    return p
+
+
+def cavmae_audio_feature(p, audio: torch.Tensor, heads: int = 12) -> torch.Tensor:
+    """CAVMAEFT.forward_feat(audio, None, 'a') (cav_mae.py:337-351) + .mean(dim=1) (basic_model.py:267)."""
+    a = audio.unsqueeze(1).transpose(2, 3)                                              # (B,1,128,1024)   :339-340
+    a = F.conv2d(a, p["patch_embed_a.proj.weight"], p["patch_embed_a.proj.bias"], stride=16).flatten(2).transpose(1, 2)   # :82
+    x = a + p["pos_embed_a"] + p["modality_a"]                                          # :342-343
+    B, n, D = x.shape
+    depth = sum(1 for k in p if k.endswith("attn.qkv.weight"))
+    for i in range(depth):
+        shared = i >= depth - 1
+        pre = f"blocks_u.{i - (depth - 1)}." if shared else f"blocks_a.{i}."
+        n1, n2 = ("norm1_a", "norm2_a") if shared else ("norm1", "norm2")              # cav_mae.py:103-108, 345-348
+        h = F.layer_norm(x, (D,), p[pre + n1 + ".weight"], p[pre + n1 + ".bias"])
+        qkv = F.linear(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"]).reshape(B, n, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+        att = F.softmax((qkv[0] @ qkv[1].transpose(-2, -1)) * (D // heads) ** -0.5, dim=-1)
+        o = (att @ qkv[2]).transpose(1, 2).reshape(B, n, D)
+        x = x + F.linear(o, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"])
+        h = F.layer_norm(x, (D,), p[pre + n2 + ".weight"], p[pre + n2 + ".bias"])
+        h = F.gelu(F.linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"]))
+        x = x + F.linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+    return F.layer_norm(x, (D,), p["norm_a.weight"], p["norm_a.bias"]).mean(dim=1)       # :349; basic_model.py:267
+
+
+def mla_step_modal3(audio_p, image_p, text_p, head, Pl, exp_count, token, padding_mask, image, spec, label,
+                    batch_index: int, len_dataloader: int, lr: float = 1e-3, gs_mode: str = "as_intended"):
+    """The FIRST pass of main.py:419-476 with --modal3 (a -> v -> t): returns per-modality features / logits / losses /
+    raw + projected head gradients / parameter gradients and the updated head, Pl, exp_count.  Encoders take their first
+    SGD step (momentum buffer = gradient); the shared head is stepped three times and its momentum carries over."""
+    out = {}
+    hmom: Dict[str, Optional[torch.Tensor]] = {"weight": None, "bias": None}
+    feats = [("a", audio_p, lambda q: cavmae_audio_feature(q, spec)),
+             ("v", image_p, lambda q: m3ae_feature(q, image=image)),
+             ("t", text_p, lambda q: m3ae_feature(q, token=token, padding_mask=padding_mask))]
+    # joint forward happens before any update (Q7); the encoders are independent, so per-phase forward is identical
+    for name, params, fn in feats:
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        W, b = head["weight"].clone().requires_grad_(True), head["bias"].clone().requires_grad_(True)
+        feat = fn(leaves)
+        logits = feat @ W.t() + b
+        loss = F.cross_entropy(logits, label)
+        keys = list(leaves)
+        grads = torch.autograd.grad(loss, [leaves[k] for k in keys] + [W, b], allow_unused=True)
+        g = {k: gv for k, gv in zip(keys, grads[:-2]) if gv is not None}
+        dW, db = grads[-2], grads[-1]
+        out["feat_" + name], out["out_" + name], out["loss_" + name] = feat.detach(), logits.detach(), loss.detach()
+        out[f"head_grad_{name}_raw"] = dW.clone()
+        Pl, dWp = gs_before_update(Pl, feat.detach(), dW, batch_index, len_dataloader, exp_count, gs_mode)
+        out[f"head_grad_{name}"], out["grads_" + name] = dWp, g
+        for k, gv in g.items():
+            params[k] = sgd_step(params[k], gv, None, lr)[0]
+        head = dict(head)
+        for k, gv in (("weight", dWp), ("bias", db)):
+            head[k], hmom[k] = sgd_step(head[k], gv, hmom[k], lr)
+        exp_count += 1
+    out["head"], out["Pl"], out["exp_count"] = head, Pl, exp_count
+    return out

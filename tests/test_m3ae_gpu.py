@@ -281,3 +281,82 @@ def test_m3ae_encoder_grads_vs_oracle(depth, B):
         for k in used:
             err = rel_l2(got[k], leaves[k].grad)
             assert err < 1e-4, (kind, k, err)
+
+
+def test_cavmae_audio_encoder_vs_oracle():
+    """CAV-MAE audio branch (row a9).  PARITY UNPINNED against the reference: timm==0.4.5 (Attention / Mlp) is neither
+    vendored nor installed and the reference has no fixture for this path; the oracle restates cav_mae.py + timm's
+    published definitions (oracle/mla_oracle.py).  HIP vs that oracle: feature 2e-5, every gradient relL2 < 1e-4."""
+    from mla_hip import M3AEEncoder
+    depth, B, seed = 3, 2, 91                                    # 2 modality-specific blocks + the shared block (norm*_a)
+    p = O.make_cavmae_audio_params(seed, depth=depth)
+    enc = M3AEEncoder("audio", depth=depth, seed=0)
+    enc.load_state_dict(p)
+    sd = enc.state_dict()
+    assert set(sd) == set(p) and all(torch.equal(sd[k].cpu(), p[k]) for k in p), "state_dict round trip (reference keys/layouts)"
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    spec = O.portable_normal(seed, (B, 1024, 128), stream=1, mean=-5.081, std=4.4849)
+    feat_ref = O.cavmae_audio_feature(leaves, spec)
+    feat = enc.forward(spec.cuda())
+    assert_close(feat, feat_ref.detach(), atol=2e-5, rtol=2e-5, name="audio feature")
+    dfeat = O.portable_normal(seed, (B, 768), stream=2)
+    feat_ref.backward(dfeat)
+    enc.backward_from_pooled(dfeat.cuda())
+    torch.cuda.synchronize()
+    got = enc.grads_as_reference()
+    assert set(got) == {k for k, v in leaves.items() if v.grad is not None}
+    for k, g in got.items():
+        err = rel_l2(g, leaves[k].grad)
+        assert err < 1e-4, (k, err)
+
+
+def test_modal3_three_way_alternation_vs_oracle():
+    """Config 5 (IEMOCAP --modal3): CAV-MAE audio + M3AE image + M3AE text, one MLA step a -> v -> t (main.py:432-466).
+    Audio branch parity unpinned (see above); image/text branches are pinned through tests/golden/m3ae_small.npz."""
+    from mla_hip import Modal3Classifier, MLATrainer
+
+    class A:
+        fusion_method, dataset, gs_flag, modulation = "concat", "IEMOCAP", True, "Normal"
+    depth, vocab, B, seed = 2, 200, 2, 123
+    model = Modal3Classifier(A(), depth=depth, text_vocab_size=vocab, seed=0)
+    pa = O.make_cavmae_audio_params(seed, depth=depth)
+    pv, pt = O.make_m3ae_params(seed + 1, depth=depth, vocab=vocab), O.make_m3ae_params(seed + 2, depth=depth, vocab=vocab)
+    hd = O.make_head_params(768, 4, seed + 3)
+    sd = {f"mae_a.{k}": v for k, v in pa.items()}
+    sd.update({f"mae_v.{k}": v for k, v in pv.items()})
+    sd.update({f"mae_t.{k}": v for k, v in pt.items()})
+    sd.update({f"fusion_module.fc_out.{k}": v for k, v in hd.items()})
+    model.load_state_dict(sd)
+    tr = MLATrainer(model)
+    tr.keep_debug = True
+    token = torch.from_numpy((O.portable_uniform(seed, B * 256, 5) * vocab).astype(np.int64)).view(B, 1, 256)
+    pm = torch.zeros(B, 1, 256)
+    pm[1, 0, 77:] = 1.0
+    image = O.portable_normal(seed, (B, 3, 256, 256), stream=3)
+    spec = O.portable_normal(seed, (B, 1024, 128), stream=4, mean=-5.081, std=4.4849)
+    label = O.portable_labels(seed, B, 4)
+    ref = O.mla_step_modal3(pa, pv, pt, hd, torch.eye(768), 0, token, pm, image, spec, label, 0, 10)
+    losses = tr.train_step(token.cuda(), pm.cuda(), image.cuda(), spec.cuda(), label.cuda(), 0, 10)
+    torch.cuda.synchronize()
+    assert set(losses) == {"loss", "loss_a", "loss_v", "loss_t"} and tr.gs_plugin.exp_count == 3
+    for nm in ("a", "v", "t"):
+        assert_close(tr.last[nm], ref["feat_" + nm], atol=2e-4, name=f"feat {nm}")
+        assert_close(tr.last["out_" + nm], ref["out_" + nm], atol=2e-4, name=f"logits {nm}")
+        assert_close(losses["loss_" + nm].reshape(()), ref["loss_" + nm], atol=2e-4, name=f"loss {nm}")
+        assert_close(tr.last[f"head_grad_{nm}_raw"], ref[f"head_grad_{nm}_raw"], atol=2e-4, name=f"raw head grad {nm}")
+    assert_close(losses["loss"].reshape(()), ref["loss_a"] * 0.55 + ref["loss_v"] * 0.45, atol=2e-4, name="reported loss (main.py:472)")
+    for nm, enc in (("a", model.mae_a), ("v", model.mae_v), ("t", model.mae_t)):
+        got = enc.grads_as_reference()
+        assert set(got) == set(ref["grads_" + nm])
+        for k, g in got.items():
+            assert rel_l2(g, ref["grads_" + nm][k]) < 2e-4, (nm, k)
+    # head after three momentum-coupled SGD steps; the first projection (phase v) starts from Pl = I and is compared with
+    # the conditioning-aware criterion of test_m3ae_step_vs_reference_golden
+    for nm, exp in (("v", 1), ("t", 2)):
+        feat, G0, Pl0 = tr.last[nm].cpu(), tr.last[f"head_grad_{nm}_raw"].cpu(), tr.last[f"Pl_before_{nm}"].cpu()
+        _, g32 = O.gs_before_update(Pl0, feat, G0, 0, 10, exp, "as_intended")
+        _, g64 = O.gs_before_update(Pl0.double(), feat.double(), G0.double(), 0, 10, exp, "as_intended")
+        err_ref = (g32.double() - g64).abs().max().item()
+        err_hip = (tr.last[f"head_grad_{nm}"].cpu().double() - g64).abs().max().item()
+        assert err_hip <= 20 * err_ref + 1e-4, (nm, err_hip, err_ref)
+    assert_close(model.fusion_module.fc_out.bias, ref["head"]["bias"], atol=1e-5, name="head bias after 3 momentum steps")
