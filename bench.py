@@ -9,7 +9,7 @@ Workload (BASELINE.json configs[1]; configs[2] for N>1): CREMA-D, --gs_flag, Res
 per-GPU batch 64 of synthetic (1x1024x128 spectrogram + 3x3x224x224 frames), fp32, weak scaling.
 One "step" = joint encoder forward + 2 x {head fwd/CE/bwd, encoder backward, GS projection, SGD}.
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with
-`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM convolution, HIP events over the timed region)
+`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM convolution, HIP events in a serialized pass after the timed region)
 and `cpu_baseline` (the CPU oracle = "port" of the reference path, timed on this host's cores, N=1 only).
 """
 import argparse
@@ -93,6 +93,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="disable the side-stream overlap (serialized kernels)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,6 +117,8 @@ def main() -> None:
     for buf in (model.audio_net.flat, model.visual_net.flat, model.fusion_module.fc_out.flat):
         comm.broadcast_(buf, 0)                                 # replicas start identical (once, at init)
     trainer = MLATrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, gs_mode="as_intended", comm=comm)
+    if a.no_overlap:
+        trainer.set_overlap(False)
 
     B = a.batch
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -135,17 +138,31 @@ def main() -> None:
     sync()
     if rank == 0:
         print(f"[bench] warm-up done ({a.warmup} steps); timing {a.steps} steps", file=sys.stderr, flush=True)
-    timer = ops.KernelTimer()
-    ops.TIMER = timer
     t0 = time.perf_counter()
     for s in range(a.steps):
         trainer.train_step(spec, image, label, (a.warmup + s) % len_dl, len_dl)
     sync()
     dt = time.perf_counter() - t0
-    ops.TIMER = None
     if rank == 0:
         print(f"[bench] timed region {dt:.3f} s", file=sys.stderr, flush=True)
     loss = float(trainer.losses["loss"].item())
+    # Roofline pass: the same K steps again with HIP events around every conv launch.  In the timed region the later
+    # modality's forward and all weight-gradient GEMMs co-run on a second stream, so a launch's elapsed time there
+    # includes CU sharing; per-kernel durations are therefore taken with the overlap off (kernels serialized),
+    # immediately after the timed region, in this same process.
+    overlapped = trainer.overlap_forward
+    trainer.set_overlap(False)
+    trainer.train_step(spec, image, label, 0, len_dl)
+    sync()
+    timer = ops.KernelTimer()
+    ops.TIMER = timer
+    t1 = time.perf_counter()
+    for s in range(a.steps):
+        trainer.train_step(spec, image, label, (a.warmup + s) % len_dl, len_dl)
+    sync()
+    dt_serial = time.perf_counter() - t1
+    ops.TIMER = None
+    trainer.set_overlap(overlapped)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -159,6 +176,11 @@ def main() -> None:
             for f in ig:
                 ig[f] += summ.get(k, {}).get(f, 0)
         achieved = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
+        if os.path.exists(tpath):     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, per launch
+            tj = json.load(open(tpath))
+            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/r01_igemm_traffic.json: " + tj["method"]
         per_kind = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
                         "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
         out = {
@@ -171,9 +193,15 @@ def main() -> None:
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(ig["ms"] / max(ig["launches"], 1), 4),
-                         "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2)},
+                         "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2),
+                         "measured": "HIP events around every conv launch over %d steps run right after the timed region "
+                                     "with the side-stream overlap off (serialized kernels, %.3f ms/step); in the timed "
+                                     "region kernels of two streams share the CUs" % (a.steps, dt_serial / a.steps * 1e3),
+                         "traffic_source": traffic_src},
+            "overlap": {"side_stream": bool(overlapped), "ms_per_step_serialized": round(dt_serial / a.steps * 1e3, 3),
+                        "conv_tflops_in_timed_region": round(sum(v["work"] for v in summ.values()) / dt / 1e12, 2)},
             "kernels": per_kind,
             "final_loss": round(loss, 5),
         }

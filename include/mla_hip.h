@@ -67,6 +67,7 @@ int mla_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio,
 
 /* ---- BatchNorm2d, training mode (backbone.py:29, 32, 86, 128) -------------------------------- */
 /* x is [M][C] (M = N*H*W).  Statistics: either mla_bn_stats (reads x) or conv-fused partials. */
+size_t mla_bn_partial_scratch_elems(int C);   /* reduction scratch tail included in every *_partial_elems / *_ws_elems below */
 size_t mla_bn_stats_partial_elems(int M, int C);
 int mla_bn_stats_partial(const float* x, int M, int C, float* partial, int* tiles, void* stream);
 /* Reduce partials in fp64 -> mean, invstd (biased var, eps), running stats (unbiased var, momentum). */

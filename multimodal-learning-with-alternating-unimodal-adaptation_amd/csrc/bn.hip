@@ -12,6 +12,7 @@
 // (conv_igemm.hip), saving one full read of the activation.
 #include "common.h"
 
+static size_t bn_red_scratch_floats(int C);
 // ---- tiling shared by the stats and backward-reduce kernels --------------------------------
 static int bn_tile_rows(int M) {
   long t = ((long)M + 2047) / 2048;  // aim at ~2048 workgroups
@@ -21,10 +22,12 @@ static int bn_tile_rows(int M) {
   return (int)t;
 }
 
+// Every partial buffer carries a scratch tail for the two-stage reduction (declared in bn.hip, used by the conv too).
+extern "C" size_t mla_bn_partial_scratch_elems(int C) { return bn_red_scratch_floats(C); }
 extern "C" size_t mla_bn_stats_partial_elems(int M, int C) {
-  return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C;
+  return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C + bn_red_scratch_floats(C);
 }
-extern "C" size_t mla_bn_bwd_ws_elems(int M, int C) { return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C + 2 * C; }
+extern "C" size_t mla_bn_bwd_ws_elems(int M, int C) { return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C + bn_red_scratch_floats(C); }
 
 // Reduce two per-channel quantities over a tile of rows.  MODE 0: (x, x^2).  MODE 1: (g, g*xhat).
 // Block: 256 threads = (C/4 column groups) x (row lanes); C/4 <= 256 and divides 256.
@@ -73,50 +76,74 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   }
 }
 
-// One wave per channel: fp64 sum over tiles of partial[t][0|1][c].
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int tiles, int M, int C,
-                                                           float eps, float momentum, float* __restrict__ mean,
-                                                           float* __restrict__ invstd, float* running_mean,
-                                                           float* running_var) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
+// Two-stage fp64 reduction of the per-tile partials partial[t][0|1][c] (up to 9408 tiles at the 64x64 conv tile).
+// Stage 1: grid (C/64, S): a block = 64 channels (lanes: coalesced 256-B rows) x 4 waves striding over its chunk of
+// tiles -> fp64 chunk sums in `scratch[s][0|1][c]`.  Stage 2: one block per 64 channels adds the S <= 64 chunk sums in
+// a fixed order and finishes the statistics.  Deterministic; replaces a wave-per-channel kernel whose strided reads
+// cost 0.7 + 0.45 ms per step.
+#define BN_RED_MAXS 64
+static int bn_red_chunks(int tiles) { int s = cdiv(tiles, 32); return s < 1 ? 1 : (s > BN_RED_MAXS ? BN_RED_MAXS : s); }
+static size_t bn_red_scratch_floats(int C) { return (size_t)BN_RED_MAXS * 2 * C * 2 + 2; }   // doubles, as floats (+ alignment)
+
+__global__ __launch_bounds__(256) void bn_tiles_stage1_kernel(const float* __restrict__ partial, int tiles, int C,
+                                                               double* __restrict__ scratch) {
+  __shared__ double red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int S = gridDim.y, per = (tiles + S - 1) / S;
+  const int t0 = blockIdx.y * per, t1 = min(tiles, t0 + per);
   double s = 0.0, q = 0.0;
-  for (int t = lane; t < tiles; t += 64) {
-    s += (double)partial[((size_t)t * 2 + 0) * C + c];
-    q += (double)partial[((size_t)t * 2 + 1) * C + c];
-  }
-  s = wave_sum_d(s);
-  q = wave_sum_d(q);
-  if (lane == 0) {
-    const double m = s / M;
-    double var = q / M - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-      const double unb = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
-      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
-      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+  if (c < C)
+    for (int t = t0 + wave; t < t1; t += 4) {
+      s += (double)partial[((size_t)t * 2 + 0) * C + c];
+      q += (double)partial[((size_t)t * 2 + 1) * C + c];
     }
+  red[0][wave][lane] = s;
+  red[1][wave][lane] = q;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    for (int w = 1; w < 4; ++w) {
+      s += red[0][w][lane];
+      q += red[1][w][lane];
+    }
+    scratch[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
+    scratch[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
   }
 }
 
-// dgamma/dbeta totals for the backward: sums partial[t][0|1][c] -> tot[0|1][c] (fp64 inside).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int tiles, int C,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ scratch, int S, int M, int C, float eps,
+                                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* running_mean, float* running_var) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
-  for (int t = lane; t < tiles; t += 64) {
-    s += (double)partial[((size_t)t * 2 + 0) * C + c];
-    q += (double)partial[((size_t)t * 2 + 1) * C + c];
+  for (int k = 0; k < S; ++k) {
+    s += scratch[((size_t)k * 2 + 0) * C + c];
+    q += scratch[((size_t)k * 2 + 1) * C + c];
   }
-  s = wave_sum_d(s);
-  q = wave_sum_d(q);
-  if (lane == 0) {
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
+  const double m = s / M;
+  double var = q / M - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unb = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
   }
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ scratch, int S, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < S; ++k) {
+    s += scratch[((size_t)k * 2 + 0) * C + c];
+    q += scratch[((size_t)k * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -187,8 +214,14 @@ extern "C" int mla_bn_finalize(const float* partial, int tiles, int M, int C, fl
                                float* invstd, float* running_mean, float* running_var, void* stream) {
   MLA_REQUIRE(partial && mean && invstd && tiles > 0 && M > 0 && C > 0, "mla_bn_finalize: bad argument");
   MLA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mla_bn_finalize: running stats must come in pairs");
-  bn_finalize_kernel<<<cdiv(C, 4), 256, 0, (hipStream_t)stream>>>(partial, tiles, M, C, eps, momentum, mean, invstd,
-                                                                 running_mean, running_var);
+  MLA_REQUIRE(((uintptr_t)partial % 8) == 0, "mla_bn_finalize: partial must be 8-byte aligned");
+  // scratch tail: right after the tiles (tiles*2*C floats is a multiple of 2 floats -> 8-byte aligned)
+  hipStream_t st = (hipStream_t)stream;
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (size_t)tiles * 2 * C);
+  const int S = bn_red_chunks(tiles);
+  bn_tiles_stage1_kernel<<<dim3(cdiv(C, 64), S), 256, 0, st>>>(partial, tiles, C, scratch);
+  MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
+  bn_finalize_kernel<<<cdiv(C, 64), 64, 0, st>>>(scratch, S, M, C, eps, momentum, mean, invstd, running_mean, running_var);
   MLA_CHECK_LAUNCH("bn_finalize_kernel");
   return MLA_OK;
 }
@@ -212,7 +245,11 @@ extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float*
   const int tr = bn_tile_rows(M), nt = cdiv(M, tr);
   bn_reduce_kernel<1><<<nt, 256, 0, st>>>(x, dout, relu_out, mean, invstd, ws, M, C, tr);
   MLA_CHECK_LAUNCH("bn_reduce_kernel<1>");
-  bn_bwd_finalize_kernel<<<cdiv(C, 4), 256, 0, st>>>(ws, nt, C, dgamma, dbeta);
+  double* scratch = reinterpret_cast<double*>(ws + (size_t)nt * 2 * C);
+  const int S = bn_red_chunks(nt);
+  bn_tiles_stage1_kernel<<<dim3(cdiv(C, 64), S), 256, 0, st>>>(ws, nt, C, scratch);
+  MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
+  bn_bwd_finalize_kernel<<<cdiv(C, 64), 64, 0, st>>>(scratch, S, C, dgamma, dbeta);
   MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   const size_t n4 = (size_t)M * C / 4;
   bn_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(dout, relu_out, x, mean, invstd, gamma, dgamma, dbeta, dx, g_out, n4,

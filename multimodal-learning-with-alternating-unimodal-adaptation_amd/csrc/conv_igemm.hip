@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+extern "C" size_t mla_bn_partial_scratch_elems(int C);   // bn.hip: scratch tail every BN partial buffer carries
 static int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
 
 static int check_conv(const char* who, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
@@ -560,7 +561,7 @@ static int cfg_bm(int cfg) { return cfg == CFG_128x128 ? 128 : (cfg == CFG_256x6
 static int cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : 64; }
 
 static int pick_cfg(const long* Ms, const int* weights, int n, int CO, bool scalar) {
-  if (scalar) return CFG_256x64;
+  if (scalar) return CFG_64x64;   // stem: 2-5 K steps per block, so many small resident blocks overlap best (measured -12 % vs 256x64)
   // measured on the ResNet-18 layer shapes (scripts/bench_conv.py): the 64x64 tile reaches 0.97 of the big
   // tiles' per-flop rate, and any tile loses ~10 % when fewer than two workgroups are resident per CU.
   const double eff[3] = {1.0, 1.0, 0.97};
@@ -591,7 +592,8 @@ static int launch_igemm(const float* X, const float* Wt, float* Y, const float* 
   const int total = cdiv(mg.M, cfg_bm(cfg)) * (mg.CO / cfg_bn(cfg));
   if (total <= 0) return MLA_OK;
   if (scalar) {
-    igemm_kernel<256, 64, 4, 1, true><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
+    if (cfg == CFG_64x64) igemm_kernel<64, 64, 2, 2, true><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
+    else igemm_kernel<256, 64, 4, 1, true><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   } else if (cfg == CFG_128x128) {
     igemm_kernel<128, 128, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   } else if (cfg == CFG_256x64) {
@@ -610,7 +612,7 @@ static int fwd_cfg(long M, int Cin, int Cout) {
 
 extern "C" size_t mla_conv2d_fwd_partial_elems(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
   const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
-  return (size_t)cdiv(M, 64) * 2 * Cout;  // upper bound over the tile choices
+  return (size_t)cdiv(M, 64) * 2 * Cout + mla_bn_partial_scratch_elems(Cout);  // upper bound over the tile choices + reduce scratch
 }
 
 extern "C" int mla_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int KH,

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "mla_conv2d_dgrad": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P]),
     "mla_conv2d_wgrad_ws_bytes": (_Z, [_I] * 9),
     "mla_conv2d_wgrad": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
+    "mla_bn_partial_scratch_elems": (_Z, [_I]),
     "mla_bn_stats_partial_elems": (_Z, [_I, _I]),
     "mla_bn_stats_partial": (_I, [_P, _I, _I, _P, _P, _P]),
     "mla_bn_finalize": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P]),

@@ -89,6 +89,9 @@ class ResNet18Encoder:
         self.grad_ready = False
         self._plan_key = None
         self._ws: dict = {}
+        # Optional second HIP stream for the weight-gradient GEMMs: they are off the dgrad -> BN-backward critical
+        # chain, so (with one dy buffer per conv: 288 GB of HBM) they run beside it and fill its kernel tails.
+        self.wgrad_stream: Optional[torch.cuda.Stream] = None
         self.reset_parameters(seed)
 
     # ------------------------------------------------------------------------------------------
@@ -216,6 +219,13 @@ class ResNet18Encoder:
         max_act, max_wgrad, max_w, max_bnws = ws["bwd_sizes"]
         f32 = dict(device=self.device, dtype=torch.float32)
         ws["G"] = [torch.empty(max_act, **f32) for _ in range(4)]
+        # one dy buffer per conv output (never reused inside a backward, so the side-stream wgrads need no extra fences)
+        ws["DY"] = {"conv1": torch.empty_like(ws["y_stem"])}
+        for blk in ws["blocks"]:
+            ws["DY"][blk["pre"] + ".conv1"] = torch.empty_like(blk["y1"])
+            ws["DY"][blk["pre"] + ".conv2"] = torch.empty_like(blk["y2"])
+            if blk["ds"]:
+                ws["DY"][blk["pre"] + ".downsample.0"] = torch.empty_like(blk["yd"])
         ws["wgrad_ws"] = torch.empty((max_wgrad + 3) // 4, **f32)
         ws["wt_ws"] = torch.empty(max_w, **f32)
         ws["bn_ws"] = torch.empty(max_bnws, **f32)
@@ -300,32 +310,45 @@ class ResNet18Encoder:
         ops.avgpool_bwd(dfeat.contiguous(), d, NB, P, out.shape[3], relu_src=out, stream=st)
         self._backward_trunk(ws, st)
 
+    def _wgrad(self, ws, x, dy, name, stride, pad) -> None:
+        """Weight gradient of conv `name`; on the side stream when one is attached (after dy has been produced)."""
+        side = self.wgrad_stream
+        if side is None:
+            ops.conv2d_wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
+            return
+        ev = torch.cuda.Event()
+        ev.record()                                   # dy is complete on the main stream at this point
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            ops.conv2d_wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
+
     def _backward_trunk(self, ws, st) -> None:
         """Expects G[0] = gradient w.r.t. the last block's output, already masked by (out > 0)."""
-        G = ws["G"]
+        G, DY = ws["G"], ws["DY"]
+        if self.wgrad_stream is not None:
+            self.wgrad_stream.wait_stream(torch.cuda.current_stream())      # wgrad_ws / grads of the previous step are consumed
         for bi_, blk in reversed(list(enumerate(ws["blocks"]))):
             pre = blk["pre"]
             oshape = blk["out"].shape
             n_out = blk["out"].numel()
             xin = blk["xin"]
             d = G[0][:n_out].view(oshape)
-            dy2 = G[1][:n_out].view(oshape)
+            dy2 = DY[pre + ".conv2"]
             self._bn_bwd(ws, st, pre + ".bn2", d, blk["y2"], dy2)
-            w2 = self.p[pre + ".conv2.weight"]
-            ops.conv2d_wgrad(blk["a1"], dy2, self.g[pre + ".conv2.weight"], 1, 1, ws["wgrad_ws"], stream=st)
+            self._wgrad(ws, blk["a1"], dy2, pre + ".conv2", 1, 1)
             da1 = G[2][:n_out].view(oshape)
-            ops.conv2d_dgrad(dy2, w2, oshape, 1, 1, ws["wt_ws"], dx=da1, relu_src=blk["a1"], stream=st)
-            self._bn_bwd(ws, st, pre + ".bn1", da1, blk["y1"], da1)          # in place: dy1 overwrites da1
-            dy1 = da1
+            ops.conv2d_dgrad(dy2, self.p[pre + ".conv2.weight"], oshape, 1, 1, ws["wt_ws"], dx=da1, relu_src=blk["a1"], stream=st)
+            dy1 = DY[pre + ".conv1"]
+            self._bn_bwd(ws, st, pre + ".bn1", da1, blk["y1"], dy1)
+            self._wgrad(ws, xin, dy1, pre + ".conv1", blk["stride"], 1)
             w1 = self.p[pre + ".conv1.weight"]
-            ops.conv2d_wgrad(xin, dy1, self.g[pre + ".conv1.weight"], blk["stride"], 1, ws["wgrad_ws"], stream=st)
             dx = G[3][:xin.numel()].view(xin.shape)
             mask = xin if bi_ > 0 else None          # block input is a ReLU output except after the max-pool
             if blk["ds"]:
-                dyd = G[1][:n_out].view(oshape)
+                dyd = DY[pre + ".downsample.0"]
                 self._bn_bwd(ws, st, pre + ".downsample.1", d, blk["yd"], dyd)
+                self._wgrad(ws, xin, dyd, pre + ".downsample.0", blk["stride"], 0)
                 wd = self.p[pre + ".downsample.0.weight"]
-                ops.conv2d_wgrad(xin, dyd, self.g[pre + ".downsample.0.weight"], blk["stride"], 0, ws["wgrad_ws"], stream=st)
                 ops.conv2d_dgrad(dy1, w1, xin.shape, blk["stride"], 1, ws["wt_ws"], dx=dx, stream=st)
                 ops.conv2d_dgrad(dyd, wd, xin.shape, blk["stride"], 0, ws["wt_ws"], dx=dx, residual=dx, relu_src=mask, stream=st)
             else:
@@ -336,6 +359,8 @@ class ResNet18Encoder:
         dpool = G[0][:ws["p0"].numel()].view(ws["p0"].shape)
         dstem = G[1][:a_stem.numel()].view(a_stem.shape)
         ops.maxpool_bwd(dpool, ws["pool_idx"], dstem, a_stem.shape, relu_src=a_stem, stream=st)
-        self._bn_bwd(ws, st, "bn1", dstem, ws["y_stem"], dstem)
-        ops.conv2d_wgrad(ws["x0"], dstem, self.g["conv1.weight"], 2, 3, ws["wgrad_ws"], stream=st)
+        self._bn_bwd(ws, st, "bn1", dstem, ws["y_stem"], DY["conv1"])
+        self._wgrad(ws, ws["x0"], DY["conv1"], "conv1", 2, 3)
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)      # all gradients complete before SGD / all-reduce
         self.grad_ready = True

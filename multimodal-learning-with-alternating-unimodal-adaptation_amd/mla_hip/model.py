@@ -111,21 +111,36 @@ class AVClassifier:
             self._feat[B] = {"a": torch.empty((B, 512), **f32), "v": torch.empty((B, 512), **f32)}
         return self._feat[B]
 
-    def forward(self, audio: torch.Tensor, visual: torch.Tensor):
-        """a, v = model(spec.unsqueeze(1).float(), image.float())  (main.py:431; basic_model.py:52-77)."""
+    def forward_audio(self, audio: torch.Tensor) -> torch.Tensor:
         B = audio.shape[0]
-        if visual.shape[0] != B:
-            raise MLAHipError("audio/visual batch mismatch")
         fa = self.audio_net.forward(audio)
-        fv = self.visual_net.forward(visual)
         buf = self._feat_buffers(B)
         n, h, w, c = fa.shape
-        ops.avgpool_fwd(fa, buf["a"], B, h * w, c)                           # adaptive_avg_pool2d + flatten
-        nt, hv, wv, cv = fv.shape
         self.audio_net._pa = h * w                                           # pooled pixels per sample (for the backward)
+        ops.avgpool_fwd(fa, buf["a"], B, h * w, c)                           # adaptive_avg_pool2d + flatten (basic_model.py:61,64)
+        return buf["a"]
+
+    def forward_visual(self, visual: torch.Tensor) -> torch.Tensor:
+        B = visual.shape[0]
+        fv = self.visual_net.forward(visual)
+        buf = self._feat_buffers(B)
+        nt, hv, wv, cv = fv.shape
         self.visual_net._pa = (nt // B) * hv * wv
-        ops.avgpool_fwd(fv, buf["v"], B, self.visual_net._pa, cv)            # regroup T + adaptive_avg_pool3d + flatten
-        return buf["a"], buf["v"]
+        ops.avgpool_fwd(fv, buf["v"], B, self.visual_net._pa, cv)            # regroup T + adaptive_avg_pool3d + flatten (:56-65)
+        return buf["v"]
+
+    def forward(self, audio: torch.Tensor, visual: torch.Tensor):
+        """a, v = model(spec.unsqueeze(1).float(), image.float())  (main.py:431; basic_model.py:52-77)."""
+        if visual.shape[0] != audio.shape[0]:
+            raise MLAHipError("audio/visual batch mismatch")
+        return self.forward_audio(audio), self.forward_visual(visual)
+
+    def forward_split(self, audio: torch.Tensor, visual: torch.Tensor):
+        """Per-encoder forward closures in alternation order, so the trainer may run later encoders' forwards on a
+        side stream: no encoder forward depends on the head or on another encoder."""
+        if visual.shape[0] != audio.shape[0]:
+            raise MLAHipError("audio/visual batch mismatch")
+        return [lambda: self.forward_audio(audio), lambda: self.forward_visual(visual)]
 
     __call__ = forward
 

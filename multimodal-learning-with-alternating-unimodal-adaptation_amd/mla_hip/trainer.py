@@ -44,6 +44,18 @@ class MLATrainer:
         self._msg = torch.empty(self.head.numel + self.head.in_features + 1, device=dev, dtype=torch.float32)
         self.losses = {k: torch.zeros(1, device=dev, dtype=torch.float32) for k in ["loss"] + ["loss_" + t for t, _g, _e in self.encoders]}
         self.last = {}
+        # Second HIP stream: the forwards of the later modalities do not depend on the head or on earlier encoders
+        # (Q7), so they run beside the first modality's forward/backward and fill its kernel tails.
+        self.overlap_forward = dev.type == "cuda" and hasattr(model, "forward_split")
+        self._side = torch.cuda.Stream(device=dev) if self.overlap_forward else None
+        self.set_overlap(self.overlap_forward)
+
+    def set_overlap(self, on: bool) -> None:
+        """Side-stream overlap (later forwards beside the first phase; weight gradients beside the dgrad chain)."""
+        self.overlap_forward = bool(on) and self._side is not None
+        for _t, _g, enc in self.encoders:
+            if hasattr(enc, "wgrad_stream"):
+                enc.wgrad_stream = self._side if self.overlap_forward else None
 
     keep_debug = False
 
@@ -91,10 +103,22 @@ class MLATrainer:
         B = label.shape[0]
         inv_batch = 1.0 / (B * self.comm.world)
         opt.zero_grad()                                                                       # main.py:164
-        feats = m.forward(*inputs)                                                            # main.py:424-431 (joint forward, Q7)
+        side_done = None
+        if self.overlap_forward:
+            fwds = m.forward_split(*inputs)                                                   # main.py:424-431 (joint forward, Q7)
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)                                                      # inputs / parameters are ready
+            with torch.cuda.stream(self._side):
+                later = [f() for f in fwds[1:]]
+                side_done = torch.cuda.Event()
+                side_done.record()
+            feats = [fwds[0]()] + later
+        else:
+            feats = m.forward(*inputs)
         pending: list = []
-        n_enc = len(self.encoders)
         for k, ((tag, grp, enc), feat) in enumerate(zip(self.encoders, feats)):
+            if k == 1 and side_done is not None:
+                torch.cuda.current_stream().wait_event(side_done)                             # later forwards have landed
             self.last[tag] = feat
             # Encoder SGD: immediately when single-process; with data parallelism it is deferred until that
             # encoder's all-reduce has landed (later phases never read an earlier encoder's parameters, so
