@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 }
 
 // Two-stage fp64 reduction of the per-tile partials partial[t][0|1][c] (up to 9408 tiles at the 64x64 conv tile).
-// Stage 1: grid (C/64, S): a block = 64 channels (lanes: coalesced 256-B rows) x 4 waves striding over its chunk of
-// tiles -> fp64 chunk sums in `scratch[s][0|1][c]`.  Stage 2: one block per 64 channels adds the S <= 64 chunk sums in
-// a fixed order and finishes the statistics.  Deterministic; replaces a wave-per-channel kernel whose strided reads
-// cost 0.7 + 0.45 ms per step.
+// Stage 1: grid (C/64, S <= 64): a block = 64 channels (lanes: coalesced 256-B rows) x 4 waves striding over its chunk
+// of >= 64 tiles -> fp64 chunk sums in `scratch[s][0|1][c]`.  Stage 2: one block per 64 channels = 64 channels x 4
+// chunk lanes, each lane loads its <= 16 chunk sums at once (no serial load chain) and the lanes are combined through
+// LDS in a fixed order.  Deterministic.
 #define BN_RED_MAXS 64
-static int bn_red_chunks(int tiles) { int s = cdiv(tiles, 32); return s < 1 ? 1 : (s > BN_RED_MAXS ? BN_RED_MAXS : s); }
+static int bn_red_chunks(int tiles) { int s = cdiv(tiles, 64); return s < 1 ? 1 : (s > BN_RED_MAXS ? BN_RED_MAXS : s); }
 static size_t bn_red_scratch_floats(int C) { return (size_t)BN_RED_MAXS * 2 * C * 2 + 2; }   // doubles, as floats (+ alignment)
 
 __global__ __launch_bounds__(256) void bn_tiles_stage1_kernel(const float* __restrict__ partial, int tiles, int C,
@@ -111,16 +111,43 @@ __global__ __launch_bounds__(256) void bn_tiles_stage1_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ scratch, int S, int M, int C, float eps,
-                                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* running_mean, float* running_var) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < S; ++k) {
-    s += scratch[((size_t)k * 2 + 0) * C + c];
-    q += scratch[((size_t)k * 2 + 1) * C + c];
+// sums of the S chunk sums for channel c = blockIdx.x*64 + lane; valid in wave 0
+__device__ __forceinline__ void chunk_sums(const double* __restrict__ scratch, int S, int C, double& s, double& q) {
+  __shared__ double red2[2][4][64];
+  const int lane = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double sv[BN_RED_MAXS / 4], qv[BN_RED_MAXS / 4];
+#pragma unroll
+  for (int j = 0; j < BN_RED_MAXS / 4; ++j) {        // all loads of this lane in flight at once
+    const int k = kl + 4 * j;
+    const bool ok = k < S && c < C;
+    sv[j] = ok ? scratch[((size_t)k * 2 + 0) * C + c] : 0.0;
+    qv[j] = ok ? scratch[((size_t)k * 2 + 1) * C + c] : 0.0;
   }
+  s = 0.0;
+  q = 0.0;
+#pragma unroll
+  for (int j = 0; j < BN_RED_MAXS / 4; ++j) {
+    s += sv[j];
+    q += qv[j];
+  }
+  red2[0][kl][lane] = s;
+  red2[1][kl][lane] = q;
+  __syncthreads();
+  if (kl == 0)
+    for (int w = 1; w < 4; ++w) {
+      s += red2[0][w][lane];
+      q += red2[1][w][lane];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ scratch, int S, int M, int C, float eps,
+                                                           float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                           float* running_mean, float* running_var) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, q;
+  chunk_sums(scratch, S, C, s, q);
+  if ((threadIdx.x >> 6) != 0 || c >= C) return;
   const double m = s / M;
   double var = q / M - m * m;
   if (var < 0.0) var = 0.0;
@@ -133,15 +160,12 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
   }
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ scratch, int S, int C,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < S; ++k) {
-    s += scratch[((size_t)k * 2 + 0) * C + c];
-    q += scratch[((size_t)k * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ scratch, int S, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, q;
+  chunk_sums(scratch, S, C, s, q);
+  if ((threadIdx.x >> 6) != 0 || c >= C) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
 }
@@ -221,7 +245,7 @@ extern "C" int mla_bn_finalize(const float* partial, int tiles, int M, int C, fl
   const int S = bn_red_chunks(tiles);
   bn_tiles_stage1_kernel<<<dim3(cdiv(C, 64), S), 256, 0, st>>>(partial, tiles, C, scratch);
   MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
-  bn_finalize_kernel<<<cdiv(C, 64), 64, 0, st>>>(scratch, S, M, C, eps, momentum, mean, invstd, running_mean, running_var);
+  bn_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, M, C, eps, momentum, mean, invstd, running_mean, running_var);
   MLA_CHECK_LAUNCH("bn_finalize_kernel");
   return MLA_OK;
 }
@@ -249,7 +273,7 @@ extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float*
   const int S = bn_red_chunks(nt);
   bn_tiles_stage1_kernel<<<dim3(cdiv(C, 64), S), 256, 0, st>>>(ws, nt, C, scratch);
   MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
-  bn_bwd_finalize_kernel<<<cdiv(C, 64), 64, 0, st>>>(scratch, S, C, dgamma, dbeta);
+  bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
   MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   const size_t n4 = (size_t)M * C / 4;
   bn_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(dout, relu_out, x, mean, invstd, gamma, dgamma, dbeta, dx, g_out, n4,
