@@ -160,6 +160,20 @@ int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int
  * viewed as (B,1,freq,time), cav_mae.py:339-340). */
 int mla_patchify(const float* img, float* out, int B, int C, int H, int W, int P, int transposed, void* stream);
 
+/* ---- evaluation path (main.py:486-679 `valid`, gs_flag branch) --------------------------------- */
+/* logits = X W^T + b only (main.py:636-639) */
+int mla_head_logits(const float* X, const float* W, const float* b, float* logits, int B, int D, int C, void* stream);
+/* Fusion + accuracy of one batch (main.py:640-676, 65-106): weights = fixed alphas or entropy gating
+ * (entropy over softmax(dim=0) = the batch axis, summed over the tensor: one scalar per modality per batch, Q9);
+ * fused = sum_m w_m out_m; arg-max (first maximum); int32 counters accumulated in `counts`:
+ * [0,C) samples per class, [C,2C) fused-correct per class, [C(2+m), C(3+m)) modality-m-correct per class.
+ * weights_out (nullable, M floats) receives the weights used.  M = 2 or 3. */
+int mla_eval_fuse(const float* out0, const float* out1, const float* out2, const int64_t* labels, int* counts,
+                  float* weights_out, int M, int B, int C, int dynamic, float alpha0, float alpha1, float alpha2,
+                  void* stream);
+/* invstd = 1/sqrt(var + eps) (eval-mode BatchNorm on running statistics) */
+int mla_bn_invstd(const float* var, float* invstd, int n, float eps, void* stream);
+
 /* ---- torch.optim.SGD(momentum, weight_decay) (main.py:749, 439, 451) ------------------------- */
 /* d = g + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf.  g == NULL means zero gradient
  * (torch-1.8.1 zero_grad semantics).  One flat launch over n contiguous elements. */

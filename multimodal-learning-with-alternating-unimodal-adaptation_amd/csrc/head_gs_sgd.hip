@@ -211,3 +211,134 @@ extern "C" int mla_sgd_step(float* p, const float* g, float* buf, size_t n, floa
   MLA_CHECK_LAUNCH("sgd_kernel");
   return MLA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Evaluation path (main.py:486-679 `valid`, gs_flag branch 622-651): per-modality logits from the shared head,
+// fixed or entropy-gated fusion (main.py:65-106; SURVEY Q9: the "entropy" is taken over softmax(dim=0), i.e. over
+// the BATCH axis, and summed over the whole tensor -> one scalar weight per modality per batch), arg-max and the
+// per-class counters of main.py:659-676 -- on the device, one workgroup, instead of a per-sample .cpu() loop.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ logits, int B,
+                                                           int D, int C) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= B) return;
+  const float* x = X + (size_t)row * D;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += x[d] * W[(size_t)c * D + d];
+    s = wave_sum(s);
+    if (lane == 0) logits[(size_t)row * C + c] = s + bias[c];
+  }
+}
+
+extern "C" int mla_head_logits(const float* X, const float* W, const float* b, float* logits, int B, int D, int C, void* stream) {
+  MLA_REQUIRE(X && W && b && logits && B > 0 && D > 0 && C > 0, "mla_head_logits: bad argument");
+  head_logits_kernel<<<cdiv(B, 4), 256, 0, (hipStream_t)stream>>>(X, W, b, logits, B, D, C);
+  MLA_CHECK_LAUNCH("head_logits_kernel");
+  return MLA_OK;
+}
+
+#define EVAL_MAXM 3
+struct EvalFuseArgs {
+  const float* out[EVAL_MAXM];   // logits per modality (B, C)
+  float alpha[EVAL_MAXM];        // fixed fusion weights (used when dynamic == 0)
+  int M, B, C, dynamic;
+};
+
+// counts layout (int32, accumulated across calls): [0..C) num per class, then for k = 0 (fused), 1..M (modalities):
+// [C*(1+k) .. C*(2+k)) correct per class.  weights_out[M]: the fusion weights used for this batch.
+__global__ __launch_bounds__(256) void eval_fuse_kernel(const EvalFuseArgs a, const int64_t* __restrict__ labels,
+                                                         int* __restrict__ counts, float* __restrict__ weights_out) {
+  __shared__ float ent[EVAL_MAXM];
+  __shared__ float wgt[EVAL_MAXM];
+  __shared__ float colpart[256];
+  const int tid = threadIdx.x;
+  if (a.dynamic) {
+    // entropy_m = - sum_{rows, cols} p log p, p = softmax over ROWS (dim=0) of out_m   (main.py:65-70)
+    for (int m = 0; m < a.M; ++m) {
+      float acc = 0.f;
+      for (int c = tid; c < a.C; c += 256) {           // one column per thread
+        float mx = -INFINITY;
+        for (int r = 0; r < a.B; ++r) mx = fmaxf(mx, a.out[m][(size_t)r * a.C + c]);
+        float s = 0.f;
+        for (int r = 0; r < a.B; ++r) s += expf(a.out[m][(size_t)r * a.C + c] - mx);
+        const float ls = logf(s);
+        for (int r = 0; r < a.B; ++r) {
+          const float lp = a.out[m][(size_t)r * a.C + c] - mx - ls;   // log softmax
+          acc -= expf(lp) * lp;
+        }
+      }
+      colpart[tid] = acc;
+      __syncthreads();
+      if (tid == 0) {
+        float e = 0.f;
+        for (int k = 0; k < 256; ++k) e += colpart[k];
+        ent[m] = e;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {                                    // main.py:72-106
+      float mx = ent[0];
+      for (int m = 1; m < a.M; ++m) mx = fmaxf(mx, ent[m]);
+      float sum = 0.f;
+      for (int m = 0; m < a.M; ++m) {
+        wgt[m] = expf(mx - ent[m]);
+        sum += wgt[m];
+      }
+      for (int m = 0; m < a.M; ++m) wgt[m] /= sum;
+    }
+  } else if (tid < a.M) {
+    wgt[tid] = a.alpha[tid];                           // main.py:647-651
+  }
+  __syncthreads();
+  if (tid < a.M && weights_out) weights_out[tid] = wgt[tid];
+  for (int r = tid; r < a.B; r += 256) {               // one sample per thread: arg-max (first maximum, like np.argmax)
+    const int lab = (int)labels[r];
+    atomicAdd(&counts[lab], 1);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < a.C; ++c) {
+      float v = 0.f;
+      for (int m = 0; m < a.M; ++m) v += wgt[m] * a.out[m][(size_t)r * a.C + c];
+      if (v > best) { best = v; arg = c; }
+    }
+    if (arg == lab) atomicAdd(&counts[a.C * 1 + lab], 1);
+    for (int m = 0; m < a.M; ++m) {
+      best = -INFINITY;
+      arg = 0;
+      for (int c = 0; c < a.C; ++c) {
+        const float v = a.out[m][(size_t)r * a.C + c];
+        if (v > best) { best = v; arg = c; }
+      }
+      if (arg == lab) atomicAdd(&counts[a.C * (2 + m) + lab], 1);
+    }
+  }
+}
+
+extern "C" int mla_eval_fuse(const float* out0, const float* out1, const float* out2, const int64_t* labels, int* counts,
+                             float* weights_out, int M, int B, int C, int dynamic, float alpha0, float alpha1, float alpha2,
+                             void* stream) {
+  MLA_REQUIRE(out0 && out1 && labels && counts && (M == 2 || (M == 3 && out2)) && B > 0 && C > 0, "mla_eval_fuse: bad argument");
+  EvalFuseArgs a;
+  a.out[0] = out0; a.out[1] = out1; a.out[2] = out2;
+  a.alpha[0] = alpha0; a.alpha[1] = alpha1; a.alpha[2] = alpha2;
+  a.M = M; a.B = B; a.C = C; a.dynamic = dynamic;
+  eval_fuse_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a, labels, counts, weights_out);
+  MLA_CHECK_LAUNCH("eval_fuse_kernel");
+  return MLA_OK;
+}
+
+// invstd[i] = 1 / sqrt(var[i] + eps): eval-mode BatchNorm uses the running statistics (one launch per encoder over
+// its flat running_var buffer)
+__global__ __launch_bounds__(256) void invstd_kernel(const float* __restrict__ var, float* __restrict__ invstd, int n, float eps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) invstd[i] = 1.0f / sqrtf(var[i] + eps);
+}
+extern "C" int mla_bn_invstd(const float* var, float* invstd, int n, float eps, void* stream) {
+  MLA_REQUIRE(var && invstd && n > 0, "mla_bn_invstd: bad argument");
+  invstd_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(var, invstd, n, eps);
+  MLA_CHECK_LAUNCH("invstd_kernel");
+  return MLA_OK;
+}

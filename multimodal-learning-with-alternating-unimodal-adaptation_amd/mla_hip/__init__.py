@@ -10,4 +10,4 @@ from .model import AVClassifier, ConcatFusion, SharedHead  # noqa: F401
 from .m3ae import ConcatFusion3, M3AEClassifier, M3AEEncoder, Modal3Classifier  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .plugin import GSPlugin  # noqa: F401
-from .trainer import MLATrainer  # noqa: F401
+from .trainer import Evaluator, MLATrainer  # noqa: F401

@@ -48,6 +48,9 @@ PROTOTYPES = {
     "mla_gs_ws_elems": (_Z, [_I, _I]),
     "mla_gs_project": (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),
     "mla_sgd_step": (_I, [_P, _P, _P, _Z, _F, _F, _F, _I, _P]),
+    "mla_head_logits": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "mla_eval_fuse": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P]),
+    "mla_bn_invstd": (_I, [_P, _P, _I, _F, _P]),
     "mla_linear_fwd": (_I, [_P] * 6 + [_I] * 8 + [_P]),
     "mla_linear_dgrad": (_I, [_P] * 6 + [_I] * 8 + [_P]),
     "mla_linear_wgrad_ws_bytes": (_Z, [_I, _I, _I]),

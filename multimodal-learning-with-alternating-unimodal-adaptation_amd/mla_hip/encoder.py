@@ -86,6 +86,15 @@ class ResNet18Encoder:
             o += c
         self.running[tot:].fill_(1.0)
         self.num_batches_tracked = {bn: 0 for bn in self.bn_names}
+        self.training = True
+        self._rinv_flat = torch.zeros(tot, device=self.device, dtype=torch.float32)    # 1/sqrt(running_var+eps), eval mode
+        self._tot_bn = tot
+        self.rinv = {}
+        o = 0
+        for bn in self.bn_names:
+            c = self.bn_ch[bn]
+            self.rinv[bn] = self._rinv_flat[o:o + c]
+            o += c
         self.grad_ready = False
         self._plan_key = None
         self._ws: dict = {}
@@ -233,10 +242,26 @@ class ResNet18Encoder:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
+    def train(self, mode: bool = True):
+        """nn.Module.train/eval semantics for the BatchNorm layers: eval uses the running statistics."""
+        self.training = bool(mode)
+        if not self.training:
+            ops.bn_invstd(self.running[self._tot_bn:], self._rinv_flat)       # one launch for all 20 BN layers
+        return self
+
+    def eval(self):
+        return self.train(False)
+
     def _conv_bn(self, ws, st, x, conv_name, stride, pad, y, out, relu, residual=None):
         """y = conv(x); BN statistics fused in the conv epilogue; out = [relu](bn(y) [+ residual])."""
         w = self.p[conv_name + ".weight"]
         bn = bn_name_for_conv(conv_name)
+        if not self.training:                                                  # eval: running statistics, nothing saved
+            ops.conv2d_fwd(x, w, stride, pad, y=y, stream=st)
+            C = w.shape[3]
+            ops.bn_apply(y, self.rm[bn], self.rinv[bn], self.p[bn + ".weight"], self.p[bn + ".bias"], out, y.numel() // C, C,
+                         relu, residual=residual, stream=st)
+            return
         _, tiles = ops.conv2d_fwd(x, w, stride, pad, y=y, bn_partial=ws["partial"], stream=st)
         C = w.shape[3]
         M = y.numel() // C

@@ -423,6 +423,13 @@ class M3AEClassifier:
     def mla_encoders(self):
         return [("a", "text", self.mae_a), ("v", "image", self.mae_v)]
 
+    def train(self, mode: bool = True):      # LayerNorm / no dropout (att_drop = drop = drop_path = 0): mode-free
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
     def forward(self, token: torch.Tensor, padding_mask: torch.Tensor, visual: torch.Tensor):
         """a, v = model(token, padding_mask, image)  (main.py:426; basic_model.py:182-200)."""
         a = self.mae_a.forward(token, padding_mask)
@@ -481,6 +488,13 @@ class Modal3Classifier:
 
     def mla_encoders(self):
         return [("a", "audio", self.mae_a), ("v", "image", self.mae_v), ("t", "text", self.mae_t)]
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
 
     def forward(self, token, padding_mask, visual, audio):
         """a, v, t = model(token, padding_mask, image, spec)  (main.py:424; basic_model.py:252-275)."""

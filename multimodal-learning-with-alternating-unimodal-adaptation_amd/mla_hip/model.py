@@ -59,6 +59,14 @@ class SharedHead:
                             self.bias_grad, buf["dX"], buf["ws"], (1.0 / B) if inv_batch is None else inv_batch)
         return buf["logits"], buf["loss"], buf["dX"]
 
+    def logits(self, X: torch.Tensor, slot: str = "eval") -> torch.Tensor:
+        """out = fc_out(x) without loss/gradients (evaluation, main.py:636-639)."""
+        buf = self._buffers(X.shape[0], slot)
+        ops.head_logits(X, self.weight, self.bias, buf["logits"])
+        return buf["logits"]
+
+    __call__ = logits
+
     def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
         return {prefix + "weight": self.weight.clone(), prefix + "bias": self.bias.clone()}
 
@@ -94,6 +102,7 @@ class AVClassifier:
         self.audio_net = ResNet18Encoder("audio", device, s(0))            # basic_model.py:42
         self.visual_net = ResNet18Encoder("visual", device, s(1))          # basic_model.py:43
         self.module = self                                                  # `model.module.` paths (DataParallel, main.py:432)
+        self.training = True
         self._feat: Dict[int, dict] = {}
 
     def mla_encoders(self):
@@ -101,9 +110,13 @@ class AVClassifier:
         return [("a", "audio", self.audio_net), ("v", "visual", self.visual_net)]
 
     def train(self, mode: bool = True):
-        if not mode:
-            raise NotImplementedError("eval-mode BatchNorm is outside the MLA training path (SURVEY section 8f-1)")
+        self.training = bool(mode)
+        self.audio_net.train(mode)
+        self.visual_net.train(mode)
         return self
+
+    def eval(self):
+        return self.train(False)
 
     def _feat_buffers(self, B: int) -> dict:
         if B not in self._feat:

@@ -322,3 +322,22 @@ def patchify(img, out, P: int = 16, transposed_hw: Optional[tuple] = None, strea
         H, W = transposed_hw
         tr = 1
     check(_lib.load().mla_patchify(_p(img), _p(out), B, C, H, W, P, tr, stream or cur_stream()), "mla_patchify")
+
+
+# ---- evaluation path ------------------------------------------------------------------------------------
+def head_logits(X, W, b, logits, stream: Optional[int] = None):
+    B, D = X.shape
+    check(_lib.load().mla_head_logits(_p(X), _p(W), _p(b), _p(logits), B, D, W.shape[0], stream or cur_stream()), "mla_head_logits")
+
+
+def eval_fuse(outs, labels, counts, weights_out, dynamic: bool, alphas, stream: Optional[int] = None):
+    M = len(outs)
+    B, C = outs[0].shape
+    o = [_p(t) for t in outs] + [None] * (3 - M)
+    al = list(alphas) + [0.0] * (3 - len(alphas))
+    check(_lib.load().mla_eval_fuse(o[0], o[1], o[2], _p(labels, torch.int64), _p(counts, torch.int32), _p(weights_out), M, B, C,
+                                    int(dynamic), al[0], al[1], al[2], stream or cur_stream()), "mla_eval_fuse")
+
+
+def bn_invstd(var, invstd, eps: float = BN_EPS, stream: Optional[int] = None):
+    check(_lib.load().mla_bn_invstd(_p(var), _p(invstd), var.numel(), eps, stream or cur_stream()), "mla_bn_invstd")

@@ -95,6 +95,8 @@ class MLATrainer:
         {'loss','loss_a','loss_v'} (no host sync; call .item() when needed, main.py:472-476)."""
         *inputs, label, batch_step, len_dataloader = batch
         m, opt = self.model, self.optimizer
+        if not getattr(m, "training", True):
+            m.train()                                                                         # main.py:135 model.train()
         if len(inputs) == 2:                                                                  # ResNet audio+visual
             spec, image = inputs
             if spec.dim() == 3:
@@ -144,3 +146,45 @@ class MLATrainer:
         torch.add(self.losses["loss_" + t0] * self.av_alpha, self.losses["loss_" + t1], alpha=1 - self.av_alpha,
                   out=self.losses["loss"])                                                    # main.py:472 (Q8)
         return self.losses
+
+
+class Evaluator:
+    """`valid()` of the reference under --gs_flag (main.py:486-679): eval-mode encoders, shared head applied to every
+    modality, fixed (av_alpha | a/v/t_alpha) or entropy-gated (--dynamic, main.py:65-106) fusion, per-class accuracy
+    counters -- kept on the device (one fusion/arg-max kernel per batch instead of the per-sample .cpu() loop of
+    main.py:659-676).  Data parallel note: the dynamic weights depend on the batch composition, so
+    evaluation must see the same global batches as the reference; this class evaluates rank-local batches."""
+
+    def __init__(self, model, dynamic: bool = False, av_alpha: float = 0.5, a_alpha: float = 0.35, v_alpha: float = 0.25,
+                 t_alpha: float = 0.4):
+        self.model = model
+        self.head = model.fusion_module.fc_out
+        self.M = len(model.mla_encoders())
+        self.C = self.head.out_features
+        self.dynamic = dynamic
+        self.alphas = [av_alpha, 1.0 - av_alpha] if self.M == 2 else [a_alpha, v_alpha, t_alpha]      # main.py:647-651
+        self.counts = torch.zeros(self.C * (2 + self.M), device=model.device, dtype=torch.int32)
+        self.weights = torch.zeros(3, device=model.device, dtype=torch.float32)
+        model.eval()                                                                                   # main.py:519
+
+    def reset(self) -> None:
+        self.counts.zero_()
+
+    def update(self, *batch):
+        """update(spec, image, label) | update(token, padding_mask, image, label) | update(token, pm, image, spec, label)."""
+        *inputs, label = batch
+        if len(inputs) == 2:
+            spec, image = inputs
+            if spec.dim() == 3:
+                spec = spec.unsqueeze(1)
+            inputs = (spec.float(), image.float())
+        feats = self.model.forward(*inputs)
+        outs = [self.head.logits(f, slot="eval_" + str(k)) for k, f in enumerate(feats)]
+        ops.eval_fuse(outs, label, self.counts, self.weights, self.dynamic, self.alphas)
+        return outs
+
+    def result(self):
+        """(acc, acc_a, acc_v[, acc_t]) = sum(acc)/sum(num) as in main.py:677-679 (one host sync)."""
+        c = self.counts.view(2 + self.M, self.C).sum(dim=1).cpu().tolist()
+        num = max(c[0], 1)
+        return tuple(x / num for x in c[1:])

@@ -713,3 +713,58 @@ def mla_step_modal3(audio_p, image_p, text_p, head, Pl, exp_count, token, paddin
         exp_count += 1
     out["head"], out["Pl"], out["exp_count"] = head, Pl, exp_count
     return out
+
+
+# ======================================================================================
+# Evaluation path: main.py:486-679 `valid`, gs_flag branch 622-651; entropy gating 65-106.
+# ======================================================================================
+def resnet18_eval_fwd(p: Dict[str, torch.Tensor], x: torch.Tensor, modality: str) -> torch.Tensor:
+    """ResNet.forward (backbone.py:142-160) with the BatchNorm layers in eval mode (running statistics)."""
+    if modality == "visual":
+        B, C, T, H, W = x.shape
+        x = x.permute(0, 2, 1, 3, 4).contiguous().view(B * T, C, H, W)
+
+    def bn(name, t):
+        return F.batch_norm(t, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"], p[name + ".bias"],
+                            False, BN_MOMENTUM, BN_EPS)
+
+    y = F.max_pool2d(torch.relu(bn("bn1", conv2d_fwd(x, p["conv1.weight"], 2, 3))), 3, 2, 1)
+    inpl = 64
+    for li, planes in enumerate([64, 128, 256, 512], start=1):
+        for bi in range(2):
+            pre, stride = f"layer{li}.{bi}", (2 if (li > 1 and bi == 0) else 1)
+            o = torch.relu(bn(pre + ".bn1", conv2d_fwd(y, p[pre + ".conv1.weight"], stride, 1)))
+            o = bn(pre + ".bn2", conv2d_fwd(o, p[pre + ".conv2.weight"], 1, 1))
+            idn = y
+            if bi == 0 and (stride != 1 or inpl != planes):
+                idn = bn(pre + ".downsample.1", conv2d_fwd(y, p[pre + ".downsample.0.weight"], stride, 0))
+            y = torch.relu(o + idn)
+            inpl = planes
+    return y
+
+
+def calculate_entropy(output: torch.Tensor) -> torch.Tensor:                 # main.py:65-70 (softmax over dim 0 = the batch, Q9)
+    prob = F.softmax(output, dim=0)
+    return -torch.sum(prob * torch.log(prob))
+
+
+def gating_weights(outs: List[torch.Tensor]) -> List[torch.Tensor]:         # main.py:72-106
+    ent = [calculate_entropy(o) for o in outs]
+    mx = max(ent)
+    w = [torch.exp(mx - e) for e in ent]
+    s = sum(w)
+    return [x / s for x in w]
+
+
+def valid_batch(outs: List[torch.Tensor], label: torch.Tensor, n_classes: int, dynamic: bool, alphas: List[float]):
+    """main.py:640-676 for one batch: returns (weights, counts) with counts[k][c]: k = 0 num, 1 fused, 2.. per modality."""
+    w = gating_weights(outs) if dynamic else [torch.tensor(a) for a in alphas]
+    fused = sum(wi * o for wi, o in zip(w, outs))
+    counts = torch.zeros(2 + len(outs), n_classes, dtype=torch.int64)
+    preds = [F.softmax(fused, dim=1).argmax(1)] + [F.softmax(o, dim=1).argmax(1) for o in outs]
+    for i in range(label.shape[0]):
+        counts[0, label[i]] += 1
+        for k, pr in enumerate(preds):
+            if pr[i] == label[i]:
+                counts[1 + k, label[i]] += 1
+    return [float(x) for x in w], counts

@@ -354,6 +354,43 @@ def run_m3ae_case(tag, B, depth, vocab, n_classes, steps, seed):
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+def run_eval_case(B, spec_hw, T, img_hw, seed):
+    """Evaluation path (main.py:486-679, gs_flag branch): the reference AVClassifier in eval() mode (BatchNorm on running
+    statistics) + fc_out per modality; the fusion/accuracy arithmetic of main.py:65-106, 640-676 is restated in the oracle
+    (main.py itself cannot be imported: tensorboard / torchvision / cuda:0)."""
+    print(f"== eval case: B={B} spec={spec_hw} T={T} img={img_hw}")
+    model, pa, pv, hd = build_reference(seed)
+    for net, params, off in ((model.module.audio_net, pa, 0), (model.module.visual_net, pv, 500)):
+        sd = net.state_dict()
+        for si, k in enumerate(sorted(k for k in sd if k.endswith("running_mean"))):
+            params[k] = O.portable_normal(seed, tuple(sd[k].shape), stream=4000 + off + si, std=0.3)
+            kv = k.replace("running_mean", "running_var")
+            params[kv] = O.portable_normal(seed, tuple(sd[kv].shape), stream=4250 + off + si, std=0.2).abs() + 0.5
+        net.load_state_dict(params)
+    model.eval()
+    spec = O.portable_normal(seed + 9, (B,) + spec_hw, stream=1, mean=-5.081, std=4.4849)
+    image = O.portable_normal(seed + 9, (B, 3, T) + img_hw, stream=2)
+    label = O.portable_labels(seed + 9, B, 6)
+    with torch.no_grad():
+        a, v = model(spec.unsqueeze(1).float(), image.float())                      # main.py:633
+        fc = model.module.fusion_module.fc_out
+        out_a, out_v = fc(a), fc(v)                                                  # main.py:636-637
+    fa = O.resnet18_eval_fwd(pa, spec.unsqueeze(1), "audio")
+    fv = O.resnet18_eval_fwd(pv, image, "visual")
+    oa, ov = O.av_pool_fwd(fa, fv, B)
+    close("eval.a", oa, a)
+    close("eval.v", ov, v)
+    fx = {"a": a.numpy(), "v": v.numpy(), "out_a": out_a.numpy(), "out_v": out_v.numpy(),
+          "meta": np.array([B, spec_hw[0], spec_hw[1], T, img_hw[0], img_hw[1], seed], dtype=np.int64)}
+    for name, dyn in (("dynamic", True), ("fixed", False)):
+        w, counts = O.valid_batch([out_a, out_v], label, 6, dyn, [0.5, 0.5])
+        fx[f"{name}.weights"] = np.array(w, dtype=np.float64)
+        fx[f"{name}.counts"] = counts.numpy()
+    path = os.path.join(HERE, "eval_small.npz")
+    np.savez_compressed(path, **fx)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     keep = ("conv1.weight", "bn1.weight", "bn1.bias", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight",
@@ -365,4 +402,5 @@ if __name__ == "__main__":
     run_gs_kat(512, 6, 64, 5, seed=21)
     run_gs_kat(768, 4, 32, 3, seed=23)
     run_m3ae_case("small", 3, 2, 1000, 11, 2, seed=61)
+    run_eval_case(16, (128, 64), 2, (96, 96), seed=71)
     print("all oracle-vs-reference checks passed")
