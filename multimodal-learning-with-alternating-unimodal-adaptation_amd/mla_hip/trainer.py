@@ -14,6 +14,7 @@ audio step), Q8 (av_alpha fixed at 0.55 in the reported loss).
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 
 import torch
@@ -47,7 +48,8 @@ class MLATrainer:
         # Second HIP stream: the forwards of the later modalities do not depend on the head or on earlier encoders
         # (Q7), so they run beside the first modality's forward/backward and fill its kernel tails.
         self.overlap_forward = dev.type == "cuda" and hasattr(model, "forward_split")
-        self._side = torch.cuda.Stream(device=dev) if self.overlap_forward else None
+        self._side = torch.cuda.Stream(device=dev) if self.overlap_forward else None       # later forwards + weight gradients
+        self._bstreams = [torch.cuda.Stream(device=dev) for _ in self.encoders] if self.overlap_forward else []   # backward chains
         self.set_overlap(self.overlap_forward)
 
     def set_overlap(self, on: bool) -> None:
@@ -60,12 +62,22 @@ class MLATrainer:
     keep_debug = False
 
     def _phase(self, name: str, enc, feat: torch.Tensor, label: torch.Tensor, inv_batch: float,
-               batch_step: int, len_dataloader: int, pending: list):
+               batch_step: int, len_dataloader: int, bstream):
+        """One modality phase (main.py:432-442).  Critical path on the current stream: head forward/backward ->
+        (data parallel: packed head exchange) -> GSPlugin -> head SGD.  The encoder backward (and its gradient
+        all-reduce) is NOT on that path -- the next modality only needs the updated head -- so when `bstream` is given
+        it is enqueued there and runs beside the following phases.  Returns the all-reduce work handles."""
         logits, loss, dX = self.head.forward_backward(feat, label, inv_batch, slot=name)               # :432-435
         self.last["out_" + name] = logits
         self.losses["loss_" + name].copy_(loss)
-        enc.backward_from_pooled(dX, enc._pa)                                                 # loss.backward()
-        works = self.comm.allreduce_flat_async(enc.grad)                                     # overlaps what follows
+        if bstream is None:
+            enc.backward_from_pooled(dX, enc._pa)                                             # loss.backward()
+            works = self.comm.allreduce_flat_async(enc.grad)                                 # overlaps what follows
+        else:
+            bstream.wait_stream(torch.cuda.current_stream())                                  # dX (and the forward) are ready
+            with torch.cuda.stream(bstream):
+                enc.backward_from_pooled(dX, enc._pa)
+                works = self.comm.allreduce_flat_async(enc.grad)
         fires = self.gs_plugin.mode == "as_intended" and self.gs_plugin.exp_count != 0
         r_mean = None
         if self.comm.active:
@@ -84,15 +96,18 @@ class MLATrainer:
         opt = self.optimizer
         opt.mark_ready("head")
         opt.step_group("head")                                                                # optimizer.step(): head
-        pending.append((name, works))
         self.gs_plugin.exp_count += 1                                                         # :442
+        return works
+
+    def _on(self, stream):
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
 
     def train_step(self, *batch):
         """AVClassifier:     train_step(spec, image, label, batch_step, len_dataloader)
         M3AEClassifier:   train_step(token, padding_mask, image, label, batch_step, len_dataloader)
         Modal3Classifier: train_step(token, padding_mask, image, spec, label, batch_step, len_dataloader)
         spec (B,H,W) or (B,1,H,W); image (B,3,T,H,W) / (B,3,256,256); label int64 (B,).  Returns device scalars
-        {'loss','loss_a','loss_v'} (no host sync; call .item() when needed, main.py:472-476)."""
+        {'loss','loss_a','loss_v'[,'loss_t']} (no host sync; call .item() when needed, main.py:472-476)."""
         *inputs, label, batch_step, len_dataloader = batch
         m, opt = self.model, self.optimizer
         if not getattr(m, "training", True):
@@ -105,10 +120,10 @@ class MLATrainer:
         B = label.shape[0]
         inv_batch = 1.0 / (B * self.comm.world)
         opt.zero_grad()                                                                       # main.py:164
+        main = torch.cuda.current_stream() if self.overlap_forward else None
         side_done = None
         if self.overlap_forward:
             fwds = m.forward_split(*inputs)                                                   # main.py:424-431 (joint forward, Q7)
-            main = torch.cuda.current_stream()
             self._side.wait_stream(main)                                                      # inputs / parameters are ready
             with torch.cuda.stream(self._side):
                 later = [f() for f in fwds[1:]]
@@ -117,30 +132,30 @@ class MLATrainer:
             feats = [fwds[0]()] + later
         else:
             feats = m.forward(*inputs)
-        pending: list = []
+        n_enc = len(self.encoders)
+        bstreams = []
         for k, ((tag, grp, enc), feat) in enumerate(zip(self.encoders, feats)):
             if k == 1 and side_done is not None:
                 torch.cuda.current_stream().wait_event(side_done)                             # later forwards have landed
             self.last[tag] = feat
-            # Encoder SGD: immediately when single-process; with data parallelism it is deferred until that
-            # encoder's all-reduce has landed (later phases never read an earlier encoder's parameters, so
-            # enqueueing them first changes no result).
-            self._phase(tag, enc, feat, label, inv_batch, batch_step, len_dataloader, pending)
+            # every encoder but the last runs its backward / all-reduce / SGD on its own stream, beside the later phases
+            bs = self._bstreams[k] if (self.overlap_forward and k < n_enc - 1) else None
+            bstreams.append(bs)
+            works = self._phase(tag, enc, feat, label, inv_batch, batch_step, len_dataloader, bs)
             opt.mark_ready(grp)
-            if not self.comm.active:
-                opt.step_group(grp)
-                if opt.legacy_zero_grad:          # torch 1.8.1: earlier encoders hold zero (not None) grads in later steps (Q6)
-                    for _t2, g2, _e2 in self.encoders[:k]:
-                        opt.grad_state[g2] = "zero"
+            with self._on(bs):
+                self.comm.wait(works)                                                         # encoder gradients reduced (data parallel)
+                opt.step_group(grp)                                                           # optimizer.step(): this encoder
+            if opt.legacy_zero_grad:              # torch 1.8.1: earlier encoders hold zero (not None) grads in later steps (Q6)
+                for j in range(k):
+                    g2 = self.encoders[j][1]
+                    opt.grad_state[g2] = "zero"
+                    with self._on(bstreams[j]):
                         opt.step_group(g2)
-        if self.comm.active:
-            for k, (tag, grp, enc) in enumerate(self.encoders):
-                self.comm.wait(pending[k][1])
-                opt.step_group(grp)
-                if opt.legacy_zero_grad:
-                    for _t2, g2, _e2 in self.encoders[:k]:
-                        opt.grad_state[g2] = "zero"
-                        opt.step_group(g2)
+        if main is not None:
+            for bs in bstreams:
+                if bs is not None:
+                    main.wait_stream(bs)                                                      # all parameters updated before the next step
         opt.drop_grads()                                                                      # main.py:468-470
         t0, t1 = self.encoders[0][0], self.encoders[1][0]
         torch.add(self.losses["loss_" + t0] * self.av_alpha, self.losses["loss_" + t1], alpha=1 - self.av_alpha,
