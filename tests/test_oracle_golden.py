@@ -109,3 +109,56 @@ def test_explicit_backward_matches_autograd():
         ref = q[k].grad
         err = (v - ref).norm().item() / max(ref.norm().item(), 1e-30)
         assert err < 2e-4, (k, err)
+
+
+def test_oracle_m3ae_step_vs_reference_golden(golden_dir):
+    """Row a8: the oracle's M3AE MLA step vs the outputs of the reference's own m3ae.py modules (2 steps, text + image)."""
+    fx = np.load(os.path.join(golden_dir, "m3ae_small.npz"))
+    B, depth, vocab, C, steps, seed = [int(v) for v in fx["meta"]]
+    st = O.M3AEState(O.make_m3ae_params(seed, depth=depth, vocab=vocab), O.make_m3ae_params(seed + 1, depth=depth, vocab=vocab),
+                     O.make_head_params(768, C, seed + 2))
+    for s in range(steps):
+        token = torch.from_numpy(np.minimum((O.portable_uniform(seed + 50 + s, B * 256, 7) * vocab).astype(np.int64), vocab - 1)).view(B, 1, 256)
+        pm = torch.zeros(B, 1, 256)
+        for b in range(B):
+            pm[b, 0, 40 + 37 * b:] = 1.0
+        image = O.portable_normal(seed + 50 + s, (B, 3, 256, 256), stream=3)
+        label = O.portable_labels(seed + 50 + s, B, C)
+        out = O.mla_step_m3ae(st, token, pm, image, label, s, 10)
+        for k in ("feat_a", "feat_v", "out_a", "out_v", "loss_a", "loss_v", "head_grad_a_raw", "head_grad_v_raw"):
+            assert_close(out[k], fx[f"s{s}.{k}"], atol=2e-4, name=f"m3ae s{s} {k}")
+        # projected head gradient: north-star absolute tolerance (ill-conditioned reference arithmetic, see make_golden.py)
+        assert_close(out["head_grad_v"], fx[f"s{s}.head_grad_v"], atol=1e-3, name=f"m3ae s{s} projected head grad")
+        for key in fx.files:
+            if key.startswith(f"s{s}.grad.") and key.endswith(".abssum"):
+                _, _, nm, rest = key.split(".", 3)
+                g = out["grads_" + nm][rest[:-len(".abssum")]]
+                want = float(fx[key])
+                assert abs(g.double().abs().sum().item() - want) <= 1e-3 * want + 1e-9, key
+        assert_close(st.text["cls_token"], fx[f"s{s}.text.cls_token"], atol=1e-5, name="text cls_token")
+        assert_close(st.image["cls_token"], fx[f"s{s}.image.cls_token"], atol=1e-5, name="image cls_token")
+
+
+def test_oracle_eval_vs_reference_golden(golden_dir):
+    """Row 8f-1: eval-mode ResNet forward + pooling + head vs the reference AVClassifier in eval(); fusion restatement self-check."""
+    fx = np.load(os.path.join(golden_dir, "eval_small.npz"))
+    B, sh, sw, T, ih, iw, seed = [int(v) for v in fx["meta"]]
+    pa, pv = O.make_resnet18_params("audio", seed), O.make_resnet18_params("visual", seed + 1)
+    hd = O.make_head_params(512, 6, seed + 2)
+    for params, off in ((pa, 0), (pv, 500)):
+        for si, k in enumerate(sorted(k for k in params if k.endswith("running_mean"))):
+            params[k] = O.portable_normal(seed, tuple(params[k].shape), stream=4000 + off + si, std=0.3)
+            kv = k.replace("running_mean", "running_var")
+            params[kv] = O.portable_normal(seed, tuple(params[kv].shape), stream=4250 + off + si, std=0.2).abs() + 0.5
+    spec = O.portable_normal(seed + 9, (B, sh, sw), stream=1, mean=-5.081, std=4.4849)
+    image = O.portable_normal(seed + 9, (B, 3, T, ih, iw), stream=2)
+    label = O.portable_labels(seed + 9, B, 6)
+    a, v = O.av_pool_fwd(O.resnet18_eval_fwd(pa, spec.unsqueeze(1), "audio"), O.resnet18_eval_fwd(pv, image, "visual"), B)
+    assert_close(a, fx["a"], atol=2e-4, rtol=1e-5, name="eval a")
+    assert_close(v, fx["v"], atol=2e-4, rtol=1e-5, name="eval v")
+    out_a, out_v = a @ hd["weight"].t() + hd["bias"], v @ hd["weight"].t() + hd["bias"]
+    assert_close(out_a, fx["out_a"], atol=2e-4, rtol=1e-5, name="eval logits a")
+    for tag, dyn in (("dynamic", True), ("fixed", False)):
+        w, counts = O.valid_batch([torch.from_numpy(fx["out_a"]), torch.from_numpy(fx["out_v"])], label, 6, dyn, [0.5, 0.5])
+        assert np.allclose(w, fx[f"{tag}.weights"], atol=1e-6) and (counts.numpy() == fx[f"{tag}.counts"]).all()
+        assert abs(sum(w) - 1.0) < 1e-6 and int(counts[0].sum()) == B

@@ -210,3 +210,24 @@ def test_rccl_path_single_rank_matches_local():
         assert torch.equal(tr_d.gs_plugin.Pl.cpu(), tr_l.gs_plugin.Pl.cpu())
     finally:
         dist.destroy_process_group()
+
+
+def test_stream_overlap_is_bitwise_equivalent():
+    """Side-stream overlap (later forwards, weight gradients, non-final encoder backward + SGD on their own streams) only
+    reorders independent kernels: parameters, momentum, Pl and losses after 3 steps equal the serialized trainer's, bit for bit."""
+    seed, B = 53, 4
+    runs = {}
+    for ov in (False, True):
+        model, tr, _ = build(seed, "as_intended", False)
+        tr.keep_debug = False
+        tr.set_overlap(ov)
+        assert tr.overlap_forward == ov
+        for step in range(3):
+            spec, image, label = inputs(seed, step, B, (128, 64), 2, (64, 64))
+            losses = tr.train_step(spec.cuda(), image.cuda(), label.cuda(), step, 10)
+        torch.cuda.synchronize()
+        runs[ov] = (model.audio_net.flat.cpu(), model.visual_net.flat.cpu(), model.fusion_module.fc_out.flat.cpu(),
+                    tr.optimizer.buf["audio"].cpu(), tr.optimizer.buf["visual"].cpu(), tr.gs_plugin.Pl.cpu(),
+                    losses["loss"].cpu(), model.audio_net.running.cpu())
+    for x, y in zip(runs[False], runs[True]):
+        assert torch.equal(x, y)
