@@ -6,6 +6,7 @@ MLAHipError if it is missing (there is no CPU or eager fallback).
 from ._lib import MLAHipError, LIB_PATH  # noqa: F401
 from .dist import Comm  # noqa: F401
 from .encoder import ResNet18Encoder  # noqa: F401
+from .feed import DeviceFeeder  # noqa: F401
 from .model import AVClassifier, ConcatFusion, SharedHead  # noqa: F401
 from .m3ae import ConcatFusion3, M3AEClassifier, M3AEEncoder, Modal3Classifier  # noqa: F401
 from .optim import FusedSGD  # noqa: F401

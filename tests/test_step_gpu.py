@@ -231,3 +231,19 @@ def test_stream_overlap_is_bitwise_equivalent():
                     losses["loss"].cpu(), model.audio_net.running.cpu())
     for x, y in zip(runs[False], runs[True]):
         assert torch.equal(x, y)
+
+
+def test_device_feeder_delivers_batches_in_order():
+    """SURVEY 8f-2 batch contract: tuples of host tensors (fp32 spec / frames, int64 labels) arrive on the device unchanged
+    and in order, also when the consumer lags (slots are recycled only after the consuming step was enqueued)."""
+    from mla_hip import DeviceFeeder
+    host = [(torch.full((4, 16, 8), float(i)), torch.randn(4, 3, 2, 8, 8) + i, torch.full((4,), i, dtype=torch.int64)) for i in range(7)]
+    seen = []
+    for i, (spec, image, label) in enumerate(DeviceFeeder(iter(host), depth=3)):
+        assert spec.is_cuda and spec.dtype == torch.float32 and label.dtype == torch.int64
+        y = (spec.sum() + image.sum()).item() if i % 2 else None      # sometimes force a sync, sometimes run ahead
+        seen.append((spec.clone(), image.clone(), label.clone()))
+    torch.cuda.synchronize()
+    assert len(seen) == 7
+    for (s, im, l), (hs, him, hl) in zip(seen, host):
+        assert torch.equal(s.cpu(), hs) and torch.equal(im.cpu(), him) and torch.equal(l.cpu(), hl)
