@@ -94,6 +94,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="disable the side-stream overlap (serialized kernels)")
+    ap.add_argument("--math", choices=["f32", "split"], default=os.environ.get("MLA_CONV_MATH", "f32"),
+                    help="conv forward/dgrad arithmetic: f32 = exact fp32 MFMA; split = exact 3-way bf16 operand split, "
+                         "6 bf16 MFMAs per fp32 product (fp32-equivalent accuracy, see DESIGN.md)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +115,7 @@ def main() -> None:
 
     from mla_hip import AVClassifier, Comm, MLATrainer, ops
 
-    model = AVClassifier(Args(), device=dev, seed=1234)        # weight_init distributions (utils/utils.py:106-114)
+    model = AVClassifier(Args(), device=dev, seed=1234, conv_math=a.math)   # weight_init distributions (utils/utils.py:106-114)
     comm = Comm()
     for buf in (model.audio_net.flat, model.visual_net.flat, model.fusion_module.fc_out.flat):
         comm.broadcast_(buf, 0)                                 # replicas start identical (once, at init)
@@ -187,7 +190,7 @@ def main() -> None:
             "metric": "samples/sec per MLA alternating step, CREMA-D A+V bs=64",
             "value": round(B * world * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "conv_math": a.math,
             "config": {"workload": "CREMA-D MLA step (--gs_flag, --lorb base ResNet18 audio+visual, GS projection as_intended), "
                                    "per-GPU batch %d: spec 1x1024x128 + frames 3x3x224x224, 6 classes" % B,
                        "global_batch": B * world, "parallelism": "dp%d" % world},

@@ -65,6 +65,27 @@ int mla_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio,
                      int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* ---- convolution, split-bf16 arithmetic (same nn.Conv2d sites as above) -------------------------
+ * The same gather-GEMM with every fp32 operand split exactly into three bf16 terms and the six products
+ * a_i*b_j (i+j <= 2) accumulated in fp32 on v_mfma_f32_32x32x16_bf16: fp32 in, fp32 out, error against
+ * the exact sum of the same order as the fp32-MFMA entry points (dropped terms <= 2^-23 |a*b|), at 6/16 of
+ * their MFMA cycles.  Weights are pre-split by mla_conv2d_wsplit into mla_conv2d_wsplit_bytes of scratch:
+ * transposed = 1 for mla_conv2d_fwd_split, 0 for mla_conv2d_dgrad_split.  Cin, Cout multiples of 64
+ * (the stem stays on mla_conv2d_fwd).  Other arguments as in mla_conv2d_fwd / mla_conv2d_dgrad.
+ * mla_conv2d_split_terms(t) (t = 3, 6, 8; anything else only queries) selects the product set for
+ * measurements; 6 is the default and the only set the parity tests bless. */
+size_t mla_conv2d_wsplit_bytes(int Cin, int Cout, int KH, int KW);
+int mla_conv2d_wsplit(const float* w_hwio, void* wsplit, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
+int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float* y,
+                         int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                         float* bn_partial, int* bn_tiles, void* stream);
+int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float* dx,
+                           int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                           const float* residual, const float* relu_src, void* stream);
+int mla_conv2d_split_terms(int terms);
+/* measurement hook: force tile 0..3 (256x128, 128x128, 128x64, 64x64) where Cout allows; -1 = automatic */
+int mla_conv2d_split_cfg(int cfg);
+
 /* ---- BatchNorm2d, training mode (backbone.py:29, 32, 86, 128) -------------------------------- */
 /* x is [M][C] (M = N*H*W).  Statistics: either mla_bn_stats (reads x) or conv-fused partials. */
 size_t mla_bn_partial_scratch_elems(int C);   /* reduction scratch tail included in every *_partial_elems / *_ws_elems below */

@@ -1,0 +1,372 @@
+// Gather-GEMM convolution with fp32 operands split into bf16 terms, on v_mfma_f32_32x32x16_bf16 (gfx950).
+//
+// Same contraction, geometry, gathers and epilogue as conv_igemm.hip (forward conv and input gradient of
+// nn.Conv2d, models/backbone.py:4-12, 28, 31, 79-83, 127), different arithmetic: every fp32 operand is written
+// as x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (round-to-nearest, exact:
+// 3 x 8 significand bits + signs cover the 24-bit fp32 significand), and a*b is accumulated in fp32 from the
+// bf16 products a_i*b_j with i + j <= 2 (six MFMAs).  The dropped terms a1*b2 + a2*b1 + a2*b2 are
+// <= 2^-23 |a*b|, the size of one fp32 rounding of the product, and the 32x32x16 MFMA rounds into the
+// accumulator once per 16 products instead of once per 2, so the result is as close to the exact sum as the
+// fp32-MFMA path's (tests/test_ops_gpu.py compares both with an fp64 reference).  The bf16 MFMA issues 16x
+// the fp32 MFMA's FLOPs per clock, so six of them cost 6/16 of the fp32 instruction they replace.
+//
+// Weights are split once per optimizer step into three bf16 planes [plane][tap][n][k] (k contiguous:
+// the layout the MFMA B operand reads with one ds_read_b128) by mla_conv2d_wsplit; activations are split
+// in the kernel on their way from registers to LDS (v_cvt_pk_bf16_f32, ~5.5 VALU ops per element).
+#include "igemm_common.h"
+
+// LDS image of one operand plane: [rows][32 bf16] = 16 dwords per row, no padding; the 16-byte chunk q of row r
+// sits at chunk slot q ^ ((r >> 2) & 3), which makes the MFMA fragment reads (ds_read_b128, 16-lane groups
+// {0-3,12-15,20-27}, ...) and the staging stores conflict-free.
+#define LROW 16
+#ifndef ABL
+#define ABL 0   // timing-only ablations (1: no split arithmetic, 3: no staging, 4: no MFMA); results are wrong unless 0
+#endif
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // low half = bf16(a), high half = bf16(b), RNE
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// two fp32 values -> three packed bf16 pairs with x = hi + mid + lo exactly
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  r0 -= __uint_as_float(mid << 16);
+  r1 -= __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk_bf16(r0, r1);
+}
+
+__device__ __forceinline__ u32x4 buf_load4u(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+
+// Products kept, largest first; TERMS = 6 is the fp32-equivalent set (i + j <= 2), 8 adds the 2^-24 terms,
+// 3 is the "bf16x3" set (relative error ~2^-16 per product: NOT fp32-equivalent, kept for measurements only).
+__device__ constexpr int TERM_A[8] = {0, 0, 1, 1, 0, 2, 1, 2};
+__device__ constexpr int TERM_B[8] = {0, 1, 0, 1, 2, 0, 2, 1};
+
+// One workgroup of WM x WN waves per CU, two LDS buffers, one barrier per K step: while the MFMAs of K step `it`
+// read buffer it&1, the same waves split the register-staged tile it+1 into the other buffer and issue the global
+// loads of tile it+2.  (Two co-resident workgroups with a single buffer each fall into lock step -- both in the
+// MFMA phase, then both in the staging phase -- and the phases add instead of overlapping; measured.)
+template <int BM, int BN, int WM, int WN, int TERMS>
+__global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const float* __restrict__ X, const void* __restrict__ Wsp,
+                                                                       float* Y, const float* R, const float* MASK,
+                                                                       float* __restrict__ part, const float* __restrict__ BIAS,
+                                                                       float* __restrict__ Y2, const IGemmGeom g) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  constexpr int AROWS = NT / 8, APASS = BM / AROWS;   // A: 8 float4 per row and K step
+  constexpr int BROWS = NT / 4, BPASS = BN / BROWS;   // B: 4 x 16 B per row, plane and K step
+  static_assert(APASS >= 1 && BPASS >= 1 && AROWS % 16 == 0, "tile too small for the workgroup");
+  constexpr int ASZ = 3 * BM * LROW, BSZ = 3 * BN * LROW;   // dwords per buffer
+
+  __shared__ __attribute__((aligned(16))) unsigned As[2 * ASZ];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[2 * BSZ];
+  __shared__ int4 rowinfo[BM];  // {n*H*W or -1, oy*sy, ox*sx, output pixel index}
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int gridN = g.CO / BN;
+  const int tm = wg / gridN, tn = wg % gridN;
+  const int gH = g.H, gW = g.W, gC = g.C, gCO = g.CO;
+
+  for (int r = tid; r < BM; r += NT) {
+    const int m = tm * BM + r;
+    int4 info = make_int4(-1, -100000, -100000, 0);
+    if (m < g.M) {
+      const int ohw = g.OH * g.OW;
+      const int n = m / ohw, rem = m - n * ohw;
+      const int oy = rem / g.OW, ox = rem - oy * g.OW;
+      info.x = n * gH * gW;
+      info.y = oy * g.sy;
+      info.z = ox * g.sx;
+      info.w = (n * g.OHF + oy * g.osy + g.ooy) * g.OWF + ox * g.osx + g.oox;
+    }
+    rowinfo[r] = info;
+  }
+  __syncthreads();
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int cpt = gC / BK;          // K steps per tap
+  const int nIter = g.T * cpt;
+  const unsigned plane_bytes = g.w_bytes / 2;   // one bf16 plane of the whole weight tensor
+
+  f32x4 areg[APASS];
+  u32x4 breg[3][BPASS];
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), wr = make_rsrc(Wsp, 3 * plane_bytes);
+  unsigned rowoff[APASS], tmask[APASS], boff[BPASS];
+#pragma unroll
+  for (int p = 0; p < APASS; ++p) {
+    const int4 info = rowinfo[p * AROWS + (tid >> 3)];
+    rowoff[p] = ((unsigned)(info.x + info.y * gW + info.z) * (unsigned)gC + (tid & 7) * 4) * 4u;
+    unsigned m = 0;
+    for (int t = 0; t < g.T; ++t) {
+      const int tp = g.tap[t];
+      const int iy = info.y + tap_dy(tp), ix = info.z + tap_dx(tp);
+      m |= ((unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW) ? (1u << t) : 0u;   // invalid rows: -100000
+    }
+    tmask[p] = m;
+  }
+#pragma unroll
+  for (int p = 0; p < BPASS; ++p) boff[p] = ((unsigned)(p * BROWS + (tid >> 2)) * (unsigned)gC + (tid & 3) * 8) * 2u;
+
+  auto load_tiles = [&](int it) {
+    const int t = it / cpt, c0 = (it - t * cpt) * BK;
+    const int tp = g.tap[t];
+    const unsigned toff = (unsigned)(((tap_dy(tp) * gW + tap_dx(tp)) * gC + c0) * 4);       // wave-uniform (SGPR)
+#pragma unroll
+    for (int p = 0; p < APASS; ++p)
+      areg[p] = buf_load4(xr, ((tmask[p] >> t) & 1u) ? rowoff[p] + toff : OOB_OFF, 0);
+    const unsigned wsoff = (unsigned)(((tap_wt(tp) * gCO + tn * BN) * gC + c0) * 2);        // wave-uniform
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p) breg[pl][p] = buf_load4u(wr, boff[p], wsoff + pl * plane_bytes);
+  };
+  // staging stores: thread (row = tid>>3, c = tid&7) owns k = 4c..4c+3 of its A rows, (n = tid>>2, q = tid&3) chunk q of its B rows
+  const int a_st = (tid >> 3) * LROW + ((((tid & 7) >> 1) ^ ((tid >> 5) & 3)) << 2) + (tid & 1) * 2;
+  const int b_st = (tid >> 2) * LROW + (((tid & 3) ^ ((tid >> 4) & 3)) << 2);
+  auto store_tiles = [&](int buf) {
+    unsigned* Ad = As + buf * ASZ + a_st;
+    unsigned* Bd = Bs + buf * BSZ + b_st;
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      unsigned h0, m0, l0, h1, m1, l1;
+#if ABL == 1
+      h0 = m0 = l0 = __float_as_uint(areg[p][0]) ^ __float_as_uint(areg[p][1]);
+      h1 = m1 = l1 = __float_as_uint(areg[p][2]) ^ __float_as_uint(areg[p][3]);
+#else
+      split_pair(areg[p][0], areg[p][1], h0, m0, l0);
+      split_pair(areg[p][2], areg[p][3], h1, m1, l1);
+#endif
+      unsigned* dst = Ad + p * AROWS * LROW;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(dst + BM * LROW) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(dst + 2 * BM * LROW) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p)
+        *reinterpret_cast<u32x4*>(Bd + (pl * BN + p * BROWS) * LROW) = breg[pl][p];
+  };
+
+  const int i = lane & 31, h = lane >> 5, swz = (i >> 2) & 3;
+  const int a_rd = (wm * (BM / WM) + i) * LROW, b_rd = (wn * (BN / WN) + i) * LROW;
+  struct Frags { bf16x8_t a[3][MI], b[3][NI]; };
+  auto load_frags = [&](int buf, int kk, Frags& f) {   // lane (i, h) holds k = kk*16 + 8h .. +7 of row / column i
+    const unsigned* Ar = As + buf * ASZ + a_rd + (((kk * 2 + h) ^ swz) << 2);
+    const unsigned* Br = Bs + buf * BSZ + b_rd + (((kk * 2 + h) ^ swz) << 2);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        f.a[pl][mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ar + (pl * BM + mi * 32) * LROW));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        f.b[pl][ni] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Br + (pl * BN + ni * 32) * LROW));
+    }
+  };
+  auto mma_frags = [&](const Frags& f) {
+#pragma unroll
+    for (int term = 0; term < TERMS; ++term)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[TERM_A[term]][mi], f.b[TERM_B[term]][ni], acc[mi][ni], 0, 0, 0);
+  };
+  Frags f0, f1;
+
+  if (nIter > 0) {  // nIter == 0: a dgrad parity class no tap reaches (1x1 stride 2): epilogue only
+    load_tiles(0);
+    store_tiles(0);
+    if (nIter > 1) load_tiles(1);
+  }
+  __syncthreads();
+  // Steady state is branch-free so the scheduler can interleave the staging work with the MFMAs; the last two
+  // K steps (nothing left to load / to stage) are peeled.  Measured alternative: a second register set with the
+  // loads of tile it+2 pinned at the top of step it (a full K step of latency cover) is 3-7 % slower.
+  int it = 0;
+  for (; it + 2 < nIter; ++it) {
+    const int cur = it & 1;
+    load_frags(cur, 0, f0);
+    load_frags(cur, 1, f1);   // both halves' fragments in flight before the first MFMA
+#if ABL != 4
+    mma_frags(f0);
+#endif
+#if ABL != 3
+    store_tiles(cur ^ 1);   // readers of that buffer finished before the previous barrier
+    load_tiles(it + 2);
+#endif
+#if ABL != 4
+    mma_frags(f1);
+#endif
+    __syncthreads();
+  }
+  if (it + 1 < nIter) {
+    const int cur = it & 1;
+    load_frags(cur, 0, f0);
+    load_frags(cur, 1, f1);
+    mma_frags(f0);
+    store_tiles(cur ^ 1);
+    mma_frags(f1);
+    __syncthreads();
+    ++it;
+  }
+  if (it < nIter) {
+    load_frags(it & 1, 0, f0);
+    load_frags(it & 1, 1, f1);
+    mma_frags(f0);
+    mma_frags(f1);
+    __syncthreads();
+  }
+  igemm_epilogue<BM, BN, WM, WN>(acc, rowinfo, reinterpret_cast<float*>(As), Y, R, MASK, part, BIAS, Y2, g, tm, tn);
+}
+
+// out[plane][t][n][k] (bf16): transposed = 1: n = co, k = ci (forward conv); 0: n = ci, k = co (input gradient).
+// in is HWIO fp32 [t][ci][co].
+__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
+                                                            int T, int CI, int CO, int transposed) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  const size_t plane = (size_t)T * CI * CO;
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    tile[r][tx] = (ci < CI && co < CO) ? in[((size_t)t * CI + ci) * CO + co] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int ci, co;
+    float v;
+    size_t o;
+    if (transposed) { co = co0 + r; ci = ci0 + tx; v = tile[tx][r]; o = ((size_t)t * CO + co) * CI + ci; }
+    else            { ci = ci0 + r; co = co0 + tx; v = tile[r][tx]; o = ((size_t)t * CI + ci) * CO + co; }
+    if (ci < CI && co < CO) {
+      unsigned hi, mid, lo;
+      split_pair(v, 0.f, hi, mid, lo);
+      out[o] = (unsigned short)hi;
+      out[plane + o] = (unsigned short)mid;
+      out[2 * plane + o] = (unsigned short)lo;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int g_split_terms = 6;
+extern "C" int mla_conv2d_split_terms(int terms) {   // measurement hook: 3, 6 (default, fp32-equivalent) or 8 products
+  if (terms == 3 || terms == 6 || terms == 8) g_split_terms = terms;
+  return g_split_terms;
+}
+
+// Tiles: 256x128 and 128x128 on 8 waves, 128x64 and 64x64 on 4 waves.
+enum { SCFG_256x128 = 0, SCFG_128x128 = 1, SCFG_128x64 = 2, SCFG_64x64 = 3, SCFG_COUNT = 4 };
+static int scfg_bm(int c) { return c == SCFG_256x128 ? 256 : (c == SCFG_64x64 ? 64 : 128); }
+static int scfg_bn(int c) { return c <= SCFG_128x128 ? 128 : 64; }
+static int g_split_cfg = -1;   // measurement hook: force one tile
+extern "C" int mla_conv2d_split_cfg(int cfg) { g_split_cfg = (cfg >= 0 && cfg < SCFG_COUNT) ? cfg : -1; return g_split_cfg; }
+
+// Minimise rounds * resident workgroups * tile area / efficiency.  The double-buffered LDS images leave room for one
+// 8-wave workgroup per CU (2 of the 128x64, 3 of the 64x64 tile); small tiles stage more bytes per MFMA.  The
+// efficiencies are the measured per-flop rates at the ResNet-18 layer shapes relative to the 256x128 tile
+// (scripts/split_probe.py); the ranking they give matches the measured ranking on l1..l4 of both modalities.
+static int pick_scfg(long M, int CO, int weight) {
+  if (g_split_cfg >= 0 && CO % scfg_bn(g_split_cfg) == 0) return g_split_cfg;
+  const double eff[SCFG_COUNT] = {1.0, 0.95, 0.8, 0.7};
+  int best = -1;
+  double best_cost = 0;
+  for (int c = 0; c < SCFG_COUNT; ++c) {
+    if (CO % scfg_bn(c) != 0) continue;
+    const double blocks = (double)cdiv(M, scfg_bm(c)) * (CO / scfg_bn(c));
+    const int per_cu = c == SCFG_64x64 ? 3 : (c == SCFG_128x64 ? 2 : 1);    // resident workgroups per CU (LDS)
+    const double rounds = (double)((long)((blocks + 256 * per_cu - 1) / (256 * per_cu)));
+    const double cost = rounds * per_cu * scfg_bm(c) * scfg_bn(c) / eff[c];
+    if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+  }
+  (void)weight;
+  return best;
+}
+
+template <int TERMS>
+static void launch_split_t(int cfg, int total, hipStream_t st, const float* X, const void* Wsp, float* Y, const float* R,
+                           const float* MASK, float* part, const float* BIAS, float* Y2, const IGemmGeom& mg) {
+  if (cfg == SCFG_256x128) igemm_split_kernel<256, 128, 4, 2, TERMS><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else if (cfg == SCFG_128x128) igemm_split_kernel<128, 128, 2, 4, TERMS><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else if (cfg == SCFG_128x64) igemm_split_kernel<128, 64, 2, 2, TERMS><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else igemm_split_kernel<64, 64, 2, 2, TERMS><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+}
+
+static int launch_split(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part,
+                        const IGemmGeom& mg, int cfg, hipStream_t st, const float* BIAS = nullptr, float* Y2 = nullptr) {
+  const int total = cdiv(mg.M, scfg_bm(cfg)) * (mg.CO / scfg_bn(cfg));
+  if (total <= 0) return MLA_OK;
+  if (g_split_terms == 6) launch_split_t<6>(cfg, total, st, X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else if (g_split_terms == 8) launch_split_t<8>(cfg, total, st, X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else launch_split_t<3>(cfg, total, st, X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  MLA_CHECK_LAUNCH("igemm_split_kernel");
+  return MLA_OK;
+}
+
+extern "C" size_t mla_conv2d_wsplit_bytes(int Cin, int Cout, int KH, int KW) {
+  return (size_t)3 * KH * KW * Cin * Cout * sizeof(unsigned short);
+}
+
+extern "C" int mla_conv2d_wsplit(const float* w, void* wsplit, int Cin, int Cout, int KH, int KW, int transposed,
+                                 void* stream) {
+  MLA_REQUIRE(w && wsplit, "mla_conv2d_wsplit: null pointer");
+  MLA_REQUIRE(Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && KH * KW <= MAX_TAPS, "mla_conv2d_wsplit: bad dims");
+  weight_split_kernel<<<dim3(cdiv(Cout, 32), cdiv(Cin, 32), KH * KW), 256, 0, (hipStream_t)stream>>>(
+      w, (unsigned short*)wsplit, KH * KW, Cin, Cout, transposed ? 1 : 0);
+  MLA_CHECK_LAUNCH("weight_split_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float* y, int N, int H, int W, int Cin, int Cout,
+                                    int KH, int KW, int stride, int pad, float* bn_partial, int* bn_tiles, void* stream) {
+  if (int rc = check_conv("mla_conv2d_fwd_split", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
+  MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_fwd_split: Cin=%d must be a multiple of 64 (the stem runs on mla_conv2d_fwd)", Cin);
+  MLA_REQUIRE(x && wsplit_t && y, "mla_conv2d_fwd_split: null pointer");
+  IGemmGeom g;
+  make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  MLA_REQUIRE(g.OH > 0 && g.OW > 0, "mla_conv2d_fwd_split: empty output");
+  const int cfg = pick_scfg(g.M, Cout, 1);
+  if (bn_tiles) *bn_tiles = cdiv(g.M, scfg_bm(cfg));
+  return launch_split(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, cfg, (hipStream_t)stream);
+}
+
+extern "C" int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
+                                      int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
+                                      void* stream) {
+  if (int rc = check_conv("mla_conv2d_dgrad_split", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
+  MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_dgrad_split: Cin=%d must be a multiple of 64 (the stem needs no dgrad)", Cin);
+  MLA_REQUIRE(dy && wsplit && dx, "mla_conv2d_dgrad_split: null pointer");
+  for (int py = 0; py < stride; ++py)
+    for (int px = 0; px < stride; ++px) {
+      IGemmGeom g;
+      make_dgrad_geom(g, py, px, N, H, W, Cin, Cout, KH, KW, stride, pad);
+      if (g.M <= 0) continue;
+      const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1);
+      if (int rc = launch_split(dy, wsplit, dx, residual, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
+    }
+  return MLA_OK;
+}

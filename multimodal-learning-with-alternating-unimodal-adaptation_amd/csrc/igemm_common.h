@@ -1,0 +1,242 @@
+// Shared pieces of the gather-GEMM convolution kernels (conv_igemm.hip: exact-fp32 MFMA;
+// conv_igemm_split.hip: fp32 operands split into three bf16 terms on the bf16 MFMA).
+#pragma once
+#include "common.h"
+
+#define MAX_TAPS 49
+#define BK 32
+
+struct IGemmGeom {
+  int N, H, W, C;          // input tensor (NHWC); C = GEMM-K per tap
+  int OH, OW;              // logical output grid
+  int CO;                  // GEMM-N
+  int sy, sx;              // input coordinate stride
+  int OHF, OWF;            // spatial dims of the output tensor
+  int osy, osx, ooy, oox;  // output pixel = (oy*osy+ooy, ox*osx+oox)
+  int T;                   // number of taps
+  int M;                   // N*OH*OW
+  int K;                   // scalar-gather mode: T*C (un-padded flattened K)
+  unsigned x_bytes, w_bytes, y_bytes;   // byte sizes of the gathered tensor, the weights and the second operand (wgrad: dY)
+  int epi;                 // 0: MASK = ReLU mask (v = MASK > 0 ? v : 0);  1: MASK = GELU pre-activation u (v *= gelu'(u))
+  int tap[MAX_TAPS];       // (dy & 0xff) | (dx & 0xff) << 8 | wt << 16   (int32: read with s_load_dword)
+};
+
+// Gathers use raw buffer loads: the hardware range check of the buffer descriptor returns 0 for any
+// offset >= num_records, so padding / out-of-range rows are "loaded" as zeros by pointing them at
+// OOB_OFF -- no zero page, no pointer select, no branch, and no select on the loaded value (which would
+// make the compiler wait for the prefetch before the MFMA block).  Offsets are 32-bit: tensors < 4 GiB.
+#define OOB_OFF 0xFFFFFFFFu
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned voff, unsigned soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+// F.gelu default (erf form), m3ae.py:77, and its derivative
+__device__ __forceinline__ float gelu_fwd(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float u) {
+  return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.39894228040143268f * expf(-0.5f * u * u);
+}
+
+static inline int pack_tap(int dy, int dx, int wt) { return (dy & 0xff) | ((dx & 0xff) << 8) | (wt << 16); }
+__device__ __forceinline__ int tap_dy(int t) { return (int)(signed char)(t & 0xff); }
+__device__ __forceinline__ int tap_dx(int t) { return (int)(signed char)((t >> 8) & 0xff); }
+__device__ __forceinline__ int tap_wt(int t) { return t >> 16; }
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue shared by the gather-GEMM kernels: residual add, bias, ReLU/GELU backward mask, GELU second
+// output, store, fused BatchNorm column statistics.  acc is in the 32x32 MFMA C/D layout
+// (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  `red` is >= 2*WM*BN floats of LDS that no
+// wave reads any more (the caller's trailing __syncthreads()).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int4* rowinfo, float* red,
+                                               float* Y, const float* R, const float* MASK, float* __restrict__ part,
+                                               const float* __restrict__ BIAS, float* __restrict__ Y2, const IGemmGeom& g,
+                                               int tm, int tn) {
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int gCO = g.CO;
+  const int h = lane >> 5, j = lane & 31;
+  float csum[NI], csq[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) csum[ni] = csq[ni] = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    size_t off[16];
+    bool ok[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int4 info = rowinfo[wm * (BM / WM) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+      ok[e] = info.x >= 0;
+      off[e] = (size_t)(ok[e] ? info.w : 0) * gCO + tn * BN + wn * (BN / WN) + j;
+    }
+    if (R) {  // all residual loads of this 32-row slab issue together (one wait, not one per element)
+      float rv[16][NI];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) rv[e][ni] = R[off[e] + ni * 32];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][e] += rv[e][ni];
+    }
+    if (BIAS) {  // Linear bias (one value per output column)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float bv = BIAS[tn * BN + wn * (BN / WN) + ni * 32 + j];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] += bv;
+      }
+    }
+    if (MASK) {
+      float mv[16][NI];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mv[e][ni] = MASK[off[e] + ni * 32];
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (g.epi == 0) acc[mi][ni][e] = mv[e][ni] > 0.f ? acc[mi][ni][e] : 0.f;   // ReLU backward
+          else acc[mi][ni][e] *= gelu_grad(mv[e][ni]);                                // GELU backward (erf form)
+        }
+    }
+    if (Y2) {  // second output: GELU of the (bias-added) pre-activation that goes to Y
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          if (ok[e]) Y2[off[e] + ni * 32] = gelu_fwd(acc[mi][ni][e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const float v = acc[mi][ni][e];
+        csum[ni] += v;          // rows past M hold exact zeros (zero A rows), so no masking is needed;
+        csq[ni] += v * v;       // the statistics are only requested by the forward conv (no R / MASK)
+        if (ok[e]) Y[off[e] + ni * 32] = v;
+      }
+  }
+  if (part) {  // fused BatchNorm statistics: per-tile column sum / sum of squares
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      csum[ni] += __shfl_xor(csum[ni], 32, 64);
+      csq[ni] += __shfl_xor(csq[ni], 32, 64);
+      if (h == 0) {
+        const int c = wn * (BN / WN) + ni * 32 + j;
+        red[(wm * 2 + 0) * BN + c] = csum[ni];
+        red[(wm * 2 + 1) * BN + c] = csq[ni];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s += red[(w * 2 + 0) * BN + tid];
+        q += red[(w * 2 + 1) * BN + tid];
+      }
+      part[((size_t)tm * 2 + 0) * gCO + tn * BN + tid] = s;
+      part[((size_t)tm * 2 + 1) * gCO + tn * BN + tid] = q;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side helpers
+// ---------------------------------------------------------------------------------------------
+static inline int conv_out(int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; }
+
+static inline int check_conv(const char* who, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  MLA_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "%s: non-positive dims", who);
+  MLA_REQUIRE(KH * KW <= MAX_TAPS && KH > 0 && KW > 0, "%s: kernel %dx%d unsupported (max %d taps)", who, KH, KW, MAX_TAPS);
+  MLA_REQUIRE(stride == 1 || stride == 2, "%s: stride %d unsupported", who, stride);
+  MLA_REQUIRE(Cout % 64 == 0 && Cout <= 1024 && Cin <= 1024, "%s: Cout=%d must be a multiple of 64; channels <= 1024", who, Cout);
+  MLA_REQUIRE(Cin % 64 == 0 || Cin <= 4, "%s: Cin=%d must be a multiple of 64 or <= 4 (stem)", who, Cin);
+  MLA_REQUIRE(pad >= 0 && pad < 64 && H < 32768 && W < 32768, "%s: pad/size out of range", who);
+  MLA_REQUIRE((long)N * H * W < (1L << 31) / 4, "%s: too many pixels for 32-bit pixel indices", who);
+  MLA_REQUIRE((long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 < 0xFFFFFFF0L, "%s: tensors must be < 4 GiB (32-bit buffer offsets)", who);
+  return MLA_OK;
+}
+
+// Tile choice: every CU runs ceil(blocks/256) rounds of MFMA-bound tiles, so minimise
+// rounds * tile area / efficiency (the 64x64 tile pays more barriers per flop).
+enum { CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2 };
+static inline int cfg_bm(int cfg) { return cfg == CFG_128x128 ? 128 : (cfg == CFG_256x64 ? 256 : 64); }
+static inline int cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : 64; }
+
+static inline int pick_cfg(const long* Ms, const int* weights, int n, int CO, bool scalar) {
+  if (scalar) return CFG_64x64;   // stem: 2-5 K steps per block, so many small resident blocks overlap best (measured -12 % vs 256x64)
+  // measured on the ResNet-18 layer shapes (scripts/bench_conv.py): the 64x64 tile reaches 0.97 of the big
+  // tiles' per-flop rate, and any tile loses ~10 % when fewer than two workgroups are resident per CU.
+  const double eff[3] = {1.0, 1.0, 0.97};
+  int best = -1;
+  double best_cost = 0;
+  for (int cfg = 0; cfg < 3; ++cfg) {
+    if (CO % cfg_bn(cfg) != 0) continue;
+    double blocks = 0, wsum = 0, wblocks = 0;
+    for (int k = 0; k < n; ++k) {
+      const double b = (double)cdiv(Ms[k], cfg_bm(cfg)) * (CO / cfg_bn(cfg));
+      blocks += b;
+      wblocks += b * weights[k];
+      wsum += weights[k];
+    }
+    if (blocks == 0) continue;
+    const double avg_w = wblocks / blocks;                        // average taps per block
+    const double rounds = (double)((long)((blocks + 255) / 256));
+    const double cost = rounds * avg_w * cfg_bm(cfg) * cfg_bn(cfg) / (eff[cfg] * (blocks < 512 ? 0.9 : 1.0));
+    (void)wsum;
+    if (best < 0 || cost < best_cost) { best = cfg; best_cost = cost; }
+  }
+  return best;
+}
+
+static inline void make_fwd_geom(IGemmGeom& g, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  g = IGemmGeom{};
+  g.N = N; g.H = H; g.W = W; g.C = Cin;
+  g.OH = conv_out(H, KH, stride, pad); g.OW = conv_out(W, KW, stride, pad);
+  g.CO = Cout; g.sy = g.sx = stride;
+  g.OHF = g.OH; g.OWF = g.OW; g.osy = g.osx = 1; g.ooy = g.oox = 0;
+  g.T = KH * KW; g.M = N * g.OH * g.OW; g.K = g.T * Cin;
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw) g.tap[kh * KW + kw] = pack_tap(kh - pad, kw - pad, kh * KW + kw);
+  g.x_bytes = (unsigned)((size_t)N * H * W * Cin * 4);
+  g.w_bytes = (unsigned)((size_t)g.T * Cin * Cout * 4);
+}
+
+// Input-gradient geometry of output parity class (py, px): the "input" of the gather-GEMM is dy
+// (N,OH,OW,Cout), the "output" is dx (N,H,W,Cin).  T == 0 (1x1 stride-2, odd parity): no tap reaches this
+// class; its blocks still run so the epilogue writes dx = residual (or 0) and applies the relu mask there.
+static inline void make_dgrad_geom(IGemmGeom& g, int py, int px, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                   int stride, int pad) {
+  const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+  g = IGemmGeom{};
+  g.N = N; g.H = OH; g.W = OW; g.C = Cout; g.CO = Cin;
+  g.OH = (H - py + stride - 1) / stride; g.OW = (W - px + stride - 1) / stride;
+  g.sy = g.sx = 1;
+  g.OHF = H; g.OWF = W; g.osy = g.osx = stride; g.ooy = py; g.oox = px;
+  g.M = N * g.OH * g.OW;
+  int T = 0;
+  for (int kh = 0; kh < KH; ++kh) {
+    if ((py + pad - kh) % stride != 0) continue;
+    for (int kw = 0; kw < KW; ++kw) {
+      if ((px + pad - kw) % stride != 0) continue;
+      g.tap[T++] = pack_tap((py + pad - kh) / stride, (px + pad - kw) / stride, kh * KW + kw);  // exact division
+    }
+  }
+  g.T = T; g.K = T * Cout;
+  g.x_bytes = (unsigned)((size_t)N * OH * OW * Cout * 4);
+  g.w_bytes = (unsigned)((size_t)KH * KW * Cin * Cout * 4);
+}

@@ -9,11 +9,16 @@ MI355X-first host design, not a module-by-module port:
   * forward and backward are explicit launch plans over a per-shape workspace that is allocated
     once (288 GB of HBM: nothing is recomputed, nothing is allocated in steady state);
   * BatchNorm statistics come out of the conv epilogue; ReLU masks and residual adds ride in the
-    dgrad / BN-apply epilogues, so no standalone element-wise kernels exist.
+    dgrad / BN-apply epilogues, so no standalone element-wise kernels exist;
+  * conv_math selects the arithmetic of the forward / input-gradient contractions of the 64..512-channel convs:
+    "f32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = fp32 operands split exactly into three bf16 terms,
+    six products on v_mfma_f32_32x32x16_bf16 (fp32 in / out / accumulate, same error against fp64; the conv weights
+    are re-split once per forward).  The stem and the weight gradients always run on the fp32 MFMA.
 """
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -51,8 +56,11 @@ def bn_name_for_conv(conv_name: str) -> str:
 class ResNet18Encoder:
     """ResNet-18 trunk without avgpool/fc (backbone.py:96-99), training-mode BatchNorm."""
 
-    def __init__(self, modality: str, device="cuda", seed: Optional[int] = None):
+    def __init__(self, modality: str, device="cuda", seed: Optional[int] = None, conv_math: Optional[str] = None):
         self.modality = modality
+        self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", "f32")
+        if self.conv_math not in ("f32", "split"):
+            raise MLAHipError(f"conv_math must be 'f32' or 'split', got {self.conv_math!r}")
         self.device = torch.device(device)
         self.specs = conv_specs(modality)
         # ---- flat layout: name -> (offset, shape); conv weights HWIO
@@ -98,6 +106,20 @@ class ResNet18Encoder:
         self.grad_ready = False
         self._plan_key = None
         self._ws: dict = {}
+        # split-bf16 images of the conv weights (conv_math == "split"): per conv a transposed image for the forward
+        # GEMM and a straight one for the input-gradient GEMM, 3 bf16 planes each, in one int16 buffer
+        self.wsp: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._wsplit_dirty = True
+        if self.conv_math == "split":
+            tot16 = sum(2 * 3 * k * k * cin * cout for _n, cin, cout, k, _s, _p in self.specs if cin % 64 == 0)
+            self._wsplit_flat = torch.empty(tot16, device=self.device, dtype=torch.int16)
+            o16 = 0
+            for name, cin, cout, k, _s, _p in self.specs:
+                if cin % 64 != 0:
+                    continue
+                n16 = 3 * k * k * cin * cout
+                self.wsp[name] = (self._wsplit_flat[o16:o16 + n16], self._wsplit_flat[o16 + n16:o16 + 2 * n16])
+                o16 += 2 * n16
         # Optional second HIP stream for the weight-gradient GEMMs: they are off the dgrad -> BN-backward critical
         # chain, so (with one dy buffer per conv: 288 GB of HBM) they run beside it and fill its kernel tails.
         self.wgrad_stream: Optional[torch.cuda.Stream] = None
@@ -147,6 +169,7 @@ class ResNet18Encoder:
                 t = sd[prefix + k].to(device=self.device, dtype=torch.float32)
                 if k == name + ".weight":
                     self.p[k].copy_(t.permute(2, 3, 1, 0))       # OIHW -> HWIO
+                    self._wsplit_dirty = True
                 elif k.endswith("running_mean"):
                     self.rm[bn].copy_(t)
                 elif k.endswith("running_var"):
@@ -242,9 +265,18 @@ class ResNet18Encoder:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
+    def _refresh_wsplit(self, st) -> None:
+        """Re-split the conv weights (they change with every optimizer step; in eval mode only when marked dirty)."""
+        for name, (w_fwd, w_dgrad) in self.wsp.items():
+            w = self.p[name + ".weight"]
+            ops.conv2d_wsplit(w, True, out=w_fwd, stream=st)
+            ops.conv2d_wsplit(w, False, out=w_dgrad, stream=st)
+        self._wsplit_dirty = False
+
     def train(self, mode: bool = True):
         """nn.Module.train/eval semantics for the BatchNorm layers: eval uses the running statistics."""
         self.training = bool(mode)
+        self._wsplit_dirty = True
         if not self.training:
             ops.bn_invstd(self.running[self._tot_bn:], self._rinv_flat)       # one launch for all 20 BN layers
         return self
@@ -256,13 +288,20 @@ class ResNet18Encoder:
         """y = conv(x); BN statistics fused in the conv epilogue; out = [relu](bn(y) [+ residual])."""
         w = self.p[conv_name + ".weight"]
         bn = bn_name_for_conv(conv_name)
+        wsp = self.wsp.get(conv_name)
         if not self.training:                                                  # eval: running statistics, nothing saved
-            ops.conv2d_fwd(x, w, stride, pad, y=y, stream=st)
+            if wsp is not None:
+                ops.conv2d_fwd_split(x, wsp[0], w.shape, stride, pad, y=y, stream=st)
+            else:
+                ops.conv2d_fwd(x, w, stride, pad, y=y, stream=st)
             C = w.shape[3]
             ops.bn_apply(y, self.rm[bn], self.rinv[bn], self.p[bn + ".weight"], self.p[bn + ".bias"], out, y.numel() // C, C,
                          relu, residual=residual, stream=st)
             return
-        _, tiles = ops.conv2d_fwd(x, w, stride, pad, y=y, bn_partial=ws["partial"], stream=st)
+        if wsp is not None:
+            _, tiles = ops.conv2d_fwd_split(x, wsp[0], w.shape, stride, pad, y=y, bn_partial=ws["partial"], stream=st)
+        else:
+            _, tiles = ops.conv2d_fwd(x, w, stride, pad, y=y, bn_partial=ws["partial"], stream=st)
         C = w.shape[3]
         M = y.numel() // C
         mean, invstd = ws["stats"][bn]
@@ -287,6 +326,8 @@ class ResNet18Encoder:
         if C != self.specs[0][1]:
             raise MLAHipError(f"{self.modality} encoder expects {self.specs[0][1]} input channels, got {C}")
         ws = self._plan(N, H, W)
+        if self.wsp and (self.training or self._wsplit_dirty):
+            self._refresh_wsplit(st)
         x = x.contiguous()
         if self.modality == "visual":
             if "x0" not in ws:
@@ -347,6 +388,15 @@ class ResNet18Encoder:
         with torch.cuda.stream(side):
             ops.conv2d_wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
 
+    def _dgrad(self, ws, st, dy, name, x_shape, stride, pad, dx, residual=None, relu_src=None) -> None:
+        wsp = self.wsp.get(name)
+        w = self.p[name + ".weight"]
+        if wsp is not None:
+            ops.conv2d_dgrad_split(dy, wsp[1], w.shape, x_shape, stride, pad, dx=dx, residual=residual, relu_src=relu_src,
+                                   stream=st)
+        else:
+            ops.conv2d_dgrad(dy, w, x_shape, stride, pad, ws["wt_ws"], dx=dx, residual=residual, relu_src=relu_src, stream=st)
+
     def _backward_trunk(self, ws, st) -> None:
         """Expects G[0] = gradient w.r.t. the last block's output, already masked by (out > 0)."""
         G, DY = ws["G"], ws["DY"]
@@ -362,22 +412,20 @@ class ResNet18Encoder:
             self._bn_bwd(ws, st, pre + ".bn2", d, blk["y2"], dy2)
             self._wgrad(ws, blk["a1"], dy2, pre + ".conv2", 1, 1)
             da1 = G[2][:n_out].view(oshape)
-            ops.conv2d_dgrad(dy2, self.p[pre + ".conv2.weight"], oshape, 1, 1, ws["wt_ws"], dx=da1, relu_src=blk["a1"], stream=st)
+            self._dgrad(ws, st, dy2, pre + ".conv2", oshape, 1, 1, da1, relu_src=blk["a1"])
             dy1 = DY[pre + ".conv1"]
             self._bn_bwd(ws, st, pre + ".bn1", da1, blk["y1"], dy1)
             self._wgrad(ws, xin, dy1, pre + ".conv1", blk["stride"], 1)
-            w1 = self.p[pre + ".conv1.weight"]
             dx = G[3][:xin.numel()].view(xin.shape)
             mask = xin if bi_ > 0 else None          # block input is a ReLU output except after the max-pool
             if blk["ds"]:
                 dyd = DY[pre + ".downsample.0"]
                 self._bn_bwd(ws, st, pre + ".downsample.1", d, blk["yd"], dyd)
                 self._wgrad(ws, xin, dyd, pre + ".downsample.0", blk["stride"], 0)
-                wd = self.p[pre + ".downsample.0.weight"]
-                ops.conv2d_dgrad(dy1, w1, xin.shape, blk["stride"], 1, ws["wt_ws"], dx=dx, stream=st)
-                ops.conv2d_dgrad(dyd, wd, xin.shape, blk["stride"], 0, ws["wt_ws"], dx=dx, residual=dx, relu_src=mask, stream=st)
+                self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx)
+                self._dgrad(ws, st, dyd, pre + ".downsample.0", xin.shape, blk["stride"], 0, dx, residual=dx, relu_src=mask)
             else:
-                ops.conv2d_dgrad(dy1, w1, xin.shape, blk["stride"], 1, ws["wt_ws"], dx=dx, residual=d, relu_src=mask, stream=st)
+                self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx, residual=d, relu_src=mask)
             G[0], G[3] = G[3], G[0]
         # stem: maxpool -> relu -> bn1 -> conv1
         a_stem = ws["a_stem"]

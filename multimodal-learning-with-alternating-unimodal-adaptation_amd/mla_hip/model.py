@@ -85,7 +85,9 @@ class ConcatFusion:
 class AVClassifier:
     """Two ResNet-18 encoders + shared head (models/basic_model.py:14-77), --gs_flag configuration."""
 
-    def __init__(self, args, device="cuda", seed: Optional[int] = None):
+    def __init__(self, args, device="cuda", seed: Optional[int] = None, conv_math: Optional[str] = None):
+        """conv_math: "f32" (exact fp32 MFMA, default) or "split" (exact bf16 operand split, fp32-equivalent; see
+        encoder.py); default from $MLA_CONV_MATH."""
         fusion = getattr(args, "fusion_method", "concat")
         dataset = getattr(args, "dataset", "CREMAD")
         if dataset != "CREMAD":                                             # basic_model.py:19-26
@@ -99,8 +101,8 @@ class AVClassifier:
         self.device = torch.device(device)
         s = (lambda k: None if seed is None else seed + k)
         self.fusion_module = ConcatFusion(512, n_classes, device, s(2))    # basic_model.py:31-32
-        self.audio_net = ResNet18Encoder("audio", device, s(0))            # basic_model.py:42
-        self.visual_net = ResNet18Encoder("visual", device, s(1))          # basic_model.py:43
+        self.audio_net = ResNet18Encoder("audio", device, s(0), conv_math)     # basic_model.py:42
+        self.visual_net = ResNet18Encoder("visual", device, s(1), conv_math)   # basic_model.py:43
         self.module = self                                                  # `model.module.` paths (DataParallel, main.py:432)
         self.training = True
         self._feat: Dict[int, dict] = {}

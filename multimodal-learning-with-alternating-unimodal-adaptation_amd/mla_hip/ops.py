@@ -131,6 +131,69 @@ def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_shape, stride: int, p
     return dx
 
 
+def conv2d_wsplit(w_hwio: torch.Tensor, transposed: bool, out: Optional[torch.Tensor] = None,
+                  stream: Optional[int] = None) -> torch.Tensor:
+    """Three bf16 planes of the conv weights (int16 storage, [3][taps][n][k]) for the split-bf16 kernels:
+    transposed=True for conv2d_fwd_split (n=Cout, k=Cin), False for conv2d_dgrad_split (n=Cin, k=Cout)."""
+    KH, KW, Cin, Cout = w_hwio.shape
+    n = int(_lib.load().mla_conv2d_wsplit_bytes(Cin, Cout, KH, KW)) // 2
+    if out is None:
+        out = torch.empty(n, device=w_hwio.device, dtype=torch.int16)
+    if out.numel() < n or out.dtype != torch.int16:
+        raise MLAHipError("conv2d_wsplit: out must hold 3*KH*KW*Cin*Cout int16")
+    check(_lib.load().mla_conv2d_wsplit(_p(w_hwio), _p(out, torch.int16), Cin, Cout, KH, KW, int(transposed),
+                                        stream or cur_stream()), "mla_conv2d_wsplit")
+    return out
+
+
+def conv2d_fwd_split(x: torch.Tensor, wsplit_t: torch.Tensor, w_shape, stride: int, pad: int,
+                     y: Optional[torch.Tensor] = None, bn_partial: Optional[torch.Tensor] = None,
+                     stream: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+    """conv2d_fwd on the split-bf16 MFMA path; `wsplit_t` = conv2d_wsplit(w, True), w_shape = (KH, KW, Cin, Cout)."""
+    N, H, W, Cin = x.shape
+    KH, KW, Cin2, Cout = w_shape
+    if Cin2 != Cin:
+        raise MLAHipError(f"conv2d_fwd_split: x has {Cin} channels, weight expects {Cin2}")
+    if y is None:
+        y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout), device=x.device,
+                        dtype=torch.float32)
+    tiles = ctypes.c_int(0)
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_fwd_split(_p(x), _p(wsplit_t, torch.int16), _p(y), N, H, W, Cin, Cout, KH, KW, stride,
+                                           pad, _p(bn_partial), ctypes.addressof(tiles), stream or cur_stream()),
+          "mla_conv2d_fwd_split")
+    if t0 is not None:
+        TIMER.end("conv_fwd", 2.0 * y.numel() * KH * KW * Cin, t0)
+    return y, tiles.value
+
+
+def conv2d_dgrad_split(dy: torch.Tensor, wsplit: torch.Tensor, w_shape, x_shape, stride: int, pad: int,
+                       dx: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                       relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    """conv2d_dgrad on the split-bf16 MFMA path; `wsplit` = conv2d_wsplit(w, False)."""
+    N, H, W, Cin = x_shape
+    KH, KW, _, Cout = w_shape
+    if dx is None:
+        dx = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_dgrad_split(_p(dy), _p(wsplit, torch.int16), _p(dx), N, H, W, Cin, Cout, KH, KW, stride,
+                                             pad, _p(residual), _p(relu_src), stream or cur_stream()),
+          "mla_conv2d_dgrad_split")
+    if t0 is not None:
+        TIMER.end("conv_dgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
+    return dx
+
+
+def conv2d_split_terms(terms: int = 0) -> int:
+    """Select (3, 6, 8) or query (anything else) the bf16 product set of the split kernels; 6 = fp32-equivalent."""
+    return int(_lib.load().mla_conv2d_split_terms(int(terms)))
+
+
+def conv2d_split_cfg(cfg: int = -1) -> int:
+    """Measurement hook: force the split kernels' tile (0..3) or restore the automatic choice (-1)."""
+    return int(_lib.load().mla_conv2d_split_cfg(int(cfg)))
+
+
 def conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad) -> int:
     return int(_lib.load().mla_conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad))
 

@@ -98,6 +98,73 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
         assert_close(nchw(dx.cpu()), 2 * dx_ref, atol=0, rtol=2e-5, name="conv dgrad accumulate")
 
 
+SPLIT_CASES = [c for c in CONV_CASES if c[3] % 64 == 0] + [(2, 33, 17, 128, 128, 3, 1, 1)]   # M = 1122: ragged vs every tile
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3], ids=lambda c: f"tile{c}")
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_split_fwd_dgrad(ops, case, cfg):
+    """Split-bf16 arithmetic (6 bf16 products per fp32 product): same parity bar as the fp32-MFMA kernels
+    (2e-5 of max|ref|), every tile configuration (256x128 / 128x128 on 8 waves, 128x64 / 64x64 on 4 waves)."""
+    N, H, W, Cin, Cout, k, s, p = case
+    seed = sum(case)
+    x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
+    w = O.portable_normal(seed, (Cout, Cin, k, k), stream=2, std=math.sqrt(2.0 / (Cin * k * k)))
+    y_ref = O.conv2d_fwd(x, w, s, p)
+    dy = O.portable_normal(seed, tuple(y_ref.shape), stream=3)
+    xd, wd, dyd = nhwc(x).cuda(), hwio(w).cuda(), nhwc(dy).cuda()
+    ops.conv2d_split_cfg(cfg)
+    try:
+        w_t, w_n = ops.conv2d_wsplit(wd, True), ops.conv2d_wsplit(wd, False)
+        part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, k, k, s, p), device="cuda")
+        y, tiles = ops.conv2d_fwd_split(xd, w_t, wd.shape, s, p, bn_partial=part)
+        assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="split conv fwd")
+        pt = part[:tiles * 2 * Cout].view(tiles, 2, Cout).double().sum(0).cpu()
+        assert_close(pt[0], y_ref.double().sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="split fused colsum")
+        assert_close(pt[1], (y_ref.double() ** 2).sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="split fused colsumsq")
+        dx_ref = O.conv2d_dgrad(dy, w, x.shape, s, p)
+        dx = ops.conv2d_dgrad_split(dyd, w_n, wd.shape, (N, H, W, Cin), s, p)
+        assert_close(nchw(dx.cpu()), dx_ref, atol=0, rtol=2e-5, name="split conv dgrad")
+        res = O.portable_normal(seed, (N, Cin, H, W), stream=4)
+        msk = O.portable_normal(seed, (N, Cin, H, W), stream=5)
+        dx2 = torch.empty_like(dx)
+        ops.conv2d_dgrad_split(dyd, w_n, wd.shape, (N, H, W, Cin), s, p, dx=dx2, residual=nhwc(res).cuda(),
+                               relu_src=nhwc(msk).cuda())
+        assert_close(nchw(dx2.cpu()), (dx_ref + res) * (msk > 0), atol=0, rtol=2e-5, name="split dgrad+res+mask")
+        ops.conv2d_dgrad_split(dyd, w_n, wd.shape, (N, H, W, Cin), s, p, dx=dx, residual=dx)
+        assert_close(nchw(dx.cpu()), 2 * dx_ref, atol=0, rtol=2e-5, name="split dgrad accumulate")
+    finally:
+        ops.conv2d_split_cfg(-1)
+
+
+def test_conv_split_is_not_reduced_precision(ops):
+    """The claim behind conv_math="split": against an fp64 reference the six-product bf16 split is at least as
+    accurate as the exact-fp32 MFMA kernel (same inputs, K = 576 .. 4608), element-wise maximum and rms.  The
+    three-product set (bf16x3, TF32-like) is measured too and must be visibly worse -- it is not used."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    for (N, H, W, Cin, Cout, k, s, p) in [(4, 28, 28, 64, 64, 3, 1, 1), (4, 14, 14, 256, 256, 3, 1, 1), (8, 7, 7, 512, 512, 3, 1, 1),
+                                          (4, 28, 28, 64, 128, 3, 2, 1)]:
+        x = torch.randn((N, H, W, Cin), device="cuda") * 3.0 + 0.5        # non-zero mean: no cancellation luck
+        w = torch.randn((k, k, Cin, Cout), device="cuda") * 0.05
+        yr = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), stride=s, padding=p).permute(0, 2, 3, 1)
+        scale = yr.pow(2).mean().sqrt()
+        y32, _ = ops.conv2d_fwd(x, w, s, p)
+        ys, _ = ops.conv2d_fwd_split(x, ops.conv2d_wsplit(w, True), w.shape, s, p)
+        ops.conv2d_split_terms(3)
+        try:
+            y3, _ = ops.conv2d_fwd_split(x, ops.conv2d_wsplit(w, True), w.shape, s, p)
+        finally:
+            ops.conv2d_split_terms(6)
+        e32 = (y32.double() - yr).abs()
+        es = (ys.double() - yr).abs()
+        e3 = (y3.double() - yr).abs()
+        rms = lambda e: float(e.pow(2).mean().sqrt() / scale)
+        assert rms(es) <= 1.1 * rms(e32) + 1e-9, (rms(es), rms(e32))
+        assert float(es.max()) <= 1.5 * float(e32.max()), (float(es.max()), float(e32.max()))
+        assert rms(e3) > 3 * rms(es), "bf16x3 should be measurably less accurate than the six-product split"
+
+
 def test_conv_rejects_bad_shapes(ops):
     from mla_hip import MLAHipError
     x = torch.zeros((1, 8, 8, 48), device="cuda")

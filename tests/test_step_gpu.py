@@ -20,13 +20,13 @@ from util import assert_close, assert_close_robust  # noqa: E402
 TOL = 2e-4
 
 
-def build(seed, gs_mode, legacy):
+def build(seed, gs_mode, legacy, conv_math="f32"):
     from mla_hip import AVClassifier, MLATrainer
 
     class Args:
         fusion_method, dataset, gs_flag, modulation = "concat", "CREMAD", True, "Normal"
 
-    model = AVClassifier(Args(), seed=0)
+    model = AVClassifier(Args(), seed=0, conv_math=conv_math)
     pa, pv = O.make_resnet18_params("audio", seed), O.make_resnet18_params("visual", seed + 1)
     hd = O.make_head_params(512, 6, seed + 2)
     sd = {f"module.audio_net.{k}": v for k, v in pa.items()}                    # DataParallel-style keys (main.py:724)
@@ -46,12 +46,13 @@ def inputs(seed, s, B, spec_hw, T, img_hw):
     return spec, image, label
 
 
+@pytest.mark.parametrize("conv_math", ["f32", "split"])
 @pytest.mark.parametrize("tag", ["small_intended", "small_published", "small_legacy", "full_b2"])
-def test_step_vs_reference_golden(tag, golden_dir):
+def test_step_vs_reference_golden(tag, conv_math, golden_dir):
     fx = np.load(os.path.join(golden_dir, f"mla_{tag}.npz"))
     B, sh, sw, T, ih, iw, steps, seed, ldl = [int(v) for v in fx["meta"]]
     gs_mode, legacy = str(fx["gs_mode"]), bool(int(fx["legacy"]))
-    model, tr, _ = build(seed, gs_mode, legacy)
+    model, tr, _ = build(seed, gs_mode, legacy, conv_math)
     for s in range(steps):
         spec, image, label = inputs(seed, s, B, (sh, sw), T, (ih, iw))
         losses = tr.train_step(spec.cuda(), image.cuda(), label.cuda(), s, ldl)
@@ -95,14 +96,17 @@ def test_step_vs_reference_golden(tag, golden_dir):
         assert abs(torch.trace(Pl).item() - float(fx[f"s{s}.Pl.trace"])) < 1e-4
 
 
+@pytest.mark.parametrize("conv_math", ["f32", "split"])
 @pytest.mark.parametrize("B,spec_hw,T,img_hw", [(3, (96, 64), 3, (64, 64)), (8, (256, 128), 3, (112, 112))])
-def test_step_vs_oracle_all_grads(B, spec_hw, T, img_hw):
+def test_step_vs_oracle_all_grads(B, spec_hw, T, img_hw, conv_math):
     """Every encoder gradient tensor, every updated parameter, BN buffers: HIP vs oracle, 2 steps.
 
     Two comparisons per step:
       (1) free-running: oracle step vs HIP step.  Features/logits/losses/head gradients element-wise (2e-4).
-          Encoder gradients only norm-wise (relL2 <= 2e-2): one ReLU decision that flips under fp32
-          re-association (measured: 1 element of layer2.1.bn2.bias) shifts everything downstream by ~1e-3.
+          Encoder gradients only norm-wise (relL2 <= 5e-2): one ReLU decision that flips under fp32
+          re-association (measured: 1 element of layer2.1.bn2.bias) shifts everything downstream by ~1e-3, and
+          on the 64x64-frame case layer4 is 2x2 pixels, so one flip moves a layer4 BN-bias gradient by 1-3e-2
+          (f32 MFMA: 1.2e-2, split-bf16: 3.2e-2 -- different summation orders flip different decisions).
       After each step the oracle's state is re-synchronised from the HIP state, so step 2 (momentum, fired
       projection, BN running stats) is also compared from an identical start.
       (2) teacher-forced: the oracle's explicit backward is run on the HIP path's own saved forward state
@@ -110,7 +114,7 @@ def test_step_vs_oracle_all_grads(B, spec_hw, T, img_hw):
     """
     from util import oracle_cache_from_hip, sync_oracle_state_from_hip
     seed = 31
-    model, tr, st = build(seed, "as_intended", False)
+    model, tr, st = build(seed, "as_intended", False, conv_math)
     head = model.fusion_module.fc_out
     for s in range(2):
         spec, image, label = inputs(seed, s, B, spec_hw, T, img_hw)
@@ -129,7 +133,7 @@ def test_step_vs_oracle_all_grads(B, spec_hw, T, img_hw):
             got = net.grads_as_reference()
             # (1) free-running, norm-wise
             for k, want in ref["grads_" + enc].items():
-                assert_close_robust(got[k], want, rel_l2=2e-2, elem_tol=1.0, frac=0.0, name=f"s{s} grad {enc}.{k}")
+                assert_close_robust(got[k], want, rel_l2=5e-2, elem_tol=1.0, frac=0.0, name=f"s{s} grad {enc}.{k}")
             # (2) teacher-forced, element-wise
             cache = oracle_cache_from_hip(net)
             dX = head._buffers(B, slot)["dX"].cpu()
@@ -170,6 +174,12 @@ def test_adjoint_identities_full_size():
         c = (dw.double() * w.double()).sum().item()
         scale = (dy.double().norm() * y.double().norm()).item()
         assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+        # the split-bf16 forward / input-gradient kernels satisfy the same identities at the same sizes
+        ys, _ = ops.conv2d_fwd_split(x, ops.conv2d_wsplit(w, True), w.shape, s, p)
+        dxs = ops.conv2d_dgrad_split(dy, ops.conv2d_wsplit(w, False), w.shape, x.shape, s, p)
+        a2 = (dy.double() * ys.double()).sum().item()
+        b2 = (dxs.double() * x.double()).sum().item()
+        assert abs(a2 - b2) <= 1e-5 * scale and abs(a2 - a) <= 1e-5 * scale, (a, a2, b2, scale)
 
 
 def test_loud_failure_without_gpu_library(monkeypatch):
