@@ -82,6 +82,11 @@ int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float* y,
 int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float* dx,
                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            const float* residual, const float* relu_src, void* stream);
+/* weight gradient on the same arithmetic (both operands split in the kernel); workspace and reduce as mla_conv2d_wgrad */
+size_t mla_conv2d_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw_hwio,
+                           int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                           void* ws, size_t ws_bytes, void* stream);
 int mla_conv2d_split_terms(int terms);
 /* measurement hook: force tile 0..3 (256x128, 128x128, 128x64, 64x64) where Cout allows; -1 = automatic */
 int mla_conv2d_split_cfg(int cfg);

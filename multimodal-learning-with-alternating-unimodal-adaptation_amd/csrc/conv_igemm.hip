@@ -490,6 +490,19 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* span, int* splits)
   *splits = (int)((M + s - 1) / s);
 }
 
+// ordered reduce of split-K slabs (shared with conv_igemm_split.hip)
+int mla_wgrad_reduce(const float* part, float* dw, size_t n4, int splits, hipStream_t st) {
+  if (splits >= 64 || n4 < 16384) {
+    wgrad_reduce_kernel<16><<<cdiv(n4, 16), 256, 0, st>>>(part, dw, n4, splits);
+  } else if (splits >= 8) {
+    wgrad_reduce_kernel<4><<<cdiv(n4, 64), 256, 0, st>>>(part, dw, n4, splits);
+  } else {
+    wgrad_reduce_kernel<1><<<cdiv(n4, 256), 256, 0, st>>>(part, dw, n4, splits);
+  }
+  MLA_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return MLA_OK;
+}
+
 extern "C" size_t mla_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
   const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
   int span, splits;
@@ -530,16 +543,7 @@ extern "C" int mla_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
     wgrad_kernel<64, 64, 2, 2, false><<<grid, 256, 0, st>>>(x, dy, part, g, span);
   }
   MLA_CHECK_LAUNCH("wgrad_kernel");
-  const size_t n4 = (size_t)g.T * Cin * Cout / 4;
-  if (splits >= 64 || n4 < 16384) {
-    wgrad_reduce_kernel<16><<<cdiv(n4, 16), 256, 0, st>>>(part, dw, n4, splits);
-  } else if (splits >= 8) {
-    wgrad_reduce_kernel<4><<<cdiv(n4, 64), 256, 0, st>>>(part, dw, n4, splits);
-  } else {
-    wgrad_reduce_kernel<1><<<cdiv(n4, 256), 256, 0, st>>>(part, dw, n4, splits);
-  }
-  MLA_CHECK_LAUNCH("wgrad_reduce_kernel");
-  return MLA_OK;
+  return mla_wgrad_reduce(part, dw, (size_t)g.T * Cin * Cout / 4, splits, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -623,11 +627,6 @@ extern "C" int mla_linear_wgrad(const float* x, const float* dy, float* dw_kn, i
     wgrad_kernel<64, 64, 2, 2, false><<<dim3((K / 64) * (N / 64), splits), 256, 0, st>>>(x, dy, part, g, span);
   }
   MLA_CHECK_LAUNCH("wgrad_kernel");
-  const size_t n4 = (size_t)K * N / 4;
-  if (splits >= 64 || n4 < 16384) wgrad_reduce_kernel<16><<<cdiv(n4, 16), 256, 0, st>>>(part, dw_kn, n4, splits);
-  else if (splits >= 8) wgrad_reduce_kernel<4><<<cdiv(n4, 64), 256, 0, st>>>(part, dw_kn, n4, splits);
-  else wgrad_reduce_kernel<1><<<cdiv(n4, 256), 256, 0, st>>>(part, dw_kn, n4, splits);
-  MLA_CHECK_LAUNCH("wgrad_reduce_kernel");
-  return MLA_OK;
+  return mla_wgrad_reduce(part, dw_kn, (size_t)K * N / 4, splits, st);
 }
 

@@ -14,6 +14,7 @@
 // the layout the MFMA B operand reads with one ds_read_b128) by mla_conv2d_wsplit; activations are split
 // in the kernel on their way from registers to LDS (v_cvt_pk_bf16_f32, ~5.5 VALU ops per element).
 #include "igemm_common.h"
+#include <type_traits>
 
 // LDS image of one operand plane: [rows][32 bf16] = 16 dwords per row, no padding; the 16-byte chunk q of row r
 // sits at chunk slot q ^ ((r >> 2) & 3), which makes the MFMA fragment reads (ds_read_b128, 16-lane groups
@@ -240,6 +241,187 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
   igemm_epilogue<BM, BN, WM, WN>(acc, rowinfo, reinterpret_cast<float*>(As), Y, R, MASK, part, BIAS, Y2, g, tm, tn);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient on the same arithmetic: dW[t][ci][co] = sum_m X[in(m,t)][ci] * dY[m][co], GEMM-K = pixels.
+// Both operands arrive pixel-major (channels contiguous) but the MFMA wants k = pixels contiguous per channel
+// row, so the staging pass transposes in registers: a thread gathers the same 4 channels of PX consecutive
+// pixels, splits them and writes PX bf16 (8 B for PX = 4) per channel row and plane.  Lanes run over the pixel
+// groups first, so a wave's loads are 128-B row pieces and its LDS stores are at most 2-way conflicted.
+// grid.x = (ci tiles) x (co tiles) x taps, grid.y = split-K ranges of `span` pixels walked in sub-chunks of
+// WGS_CHUNK pixels; partial slabs and the ordered reduce are those of the fp32 kernel (conv_igemm.hip).
+// ---------------------------------------------------------------------------------------------
+#define WGS_CHUNK 2048
+template <int BI, int BJ, int WI, int WJ>
+__global__ __launch_bounds__(256, 1) void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                              float* __restrict__ part, const IGemmGeom g, int span) {
+  static_assert(WI * WJ == 4, "4 waves");
+  constexpr int MI = BI / WI / 32, NI = BJ / WJ / 32;
+  constexpr int XG = 256 / (BI / 4), XPX = BK / XG;    // pixel groups per K step, pixels per thread (X operand)
+  constexpr int YG = 256 / (BJ / 4), YPX = BK / YG;
+  static_assert((XPX == 4 || XPX == 2) && (YPX == 4 || YPX == 2), "tile / workgroup mismatch");
+  constexpr int ASZ = 3 * BI * LROW, BSZ = 3 * BJ * LROW;
+  __shared__ __attribute__((aligned(16))) unsigned As[2 * ASZ];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[2 * BSZ];
+  __shared__ unsigned rowoff[WGS_CHUNK];   // byte offset of the gathered X row (this block's tap, channel tile) or OOB_OFF
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave / WJ, wj = wave % WJ;
+  const int tilesI = g.C / BI, tilesJ = g.CO / BJ;
+  int b = blockIdx.x;
+  const int tj = b % tilesJ; b /= tilesJ;
+  const int ti = b % tilesI; b /= tilesI;
+  const int t = b;
+  const int m_begin = blockIdx.y * span, m_end = min(g.M, m_begin + span);
+  const int gH = g.H, gW = g.W, gC = g.C, gCO = g.CO;
+  const int dy = tap_dy(g.tap[t]), dx = tap_dx(g.tap[t]);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), yr = make_rsrc(dY, g.y_bytes);
+  f32x4 xreg[XPX], yreg[YPX];
+  const int xg = tid % XG, xc = tid / XG;   // pixel group, 4-channel chunk
+  const int yg = tid % YG, yc = tid / YG;
+  // LDS store address of channel row 4c+e, pixels g*PX .. +PX-1 (bytes 2*PX*g of the 64-B row, chunk-swizzled by row>>2 & 3 = c & 3)
+  const int x_st = (xc * 4) * LROW + (XPX == 4 ? ((((xg >> 1) ^ (xc & 3)) << 2) + (xg & 1) * 2) : ((((xg >> 2) ^ (xc & 3)) << 2) + (xg & 3)));
+  const int y_st = (yc * 4) * LROW + (YPX == 4 ? ((((yg >> 1) ^ (yc & 3)) << 2) + (yg & 1) * 2) : ((((yg >> 2) ^ (yc & 3)) << 2) + (yg & 3)));
+  const int i = lane & 31, h = lane >> 5, swz = (i >> 2) & 3;
+  const int a_rd = (wi * (BI / WI) + i) * LROW, b_rd = (wj * (BJ / WJ) + i) * LROW;
+
+  struct Frags { bf16x8_t a[3][MI], b[3][NI]; };
+  auto load_frags = [&](int buf, int kk, Frags& f) {
+    const unsigned* Ar = As + buf * ASZ + a_rd + (((kk * 2 + h) ^ swz) << 2);
+    const unsigned* Br = Bs + buf * BSZ + b_rd + (((kk * 2 + h) ^ swz) << 2);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        f.a[pl][mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ar + (pl * BI + mi * 32) * LROW));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        f.b[pl][ni] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Br + (pl * BJ + ni * 32) * LROW));
+    }
+  };
+  auto mma_frags = [&](const Frags& f) {
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[TERM_A[term]][mi], f.b[TERM_B[term]][ni], acc[mi][ni], 0, 0, 0);
+  };
+  Frags f0, f1;
+
+  for (int c_begin = m_begin; c_begin < m_end; c_begin += WGS_CHUNK) {
+    const int c_end = min(m_end, c_begin + WGS_CHUNK);
+    __syncthreads();  // previous sub-chunk's readers are done with rowoff / As / Bs
+    for (int r = tid; r < WGS_CHUNK; r += 256) {
+      const int m = c_begin + r;
+      unsigned off = OOB_OFF;
+      if (m < c_end) {
+        const int ohw = g.OH * g.OW;
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oy = rem / g.OW, ox = rem - oy * g.OW;
+        const int iy = oy * g.sy + dy, ix = ox * g.sx + dx;
+        if ((unsigned)iy < (unsigned)gH && (unsigned)ix < (unsigned)gW)
+          off = ((unsigned)(n * gH * gW + iy * gW + ix) * (unsigned)gC + ti * BI) * 4u;
+      }
+      rowoff[r] = off;
+    }
+    __syncthreads();
+
+    auto load_tiles = [&](int p0) {  // p0: first pixel (sub-chunk-relative) of this K step
+#pragma unroll
+      for (int q = 0; q < XPX; ++q) {
+        const unsigned ro = rowoff[p0 + xg * XPX + q];
+        xreg[q] = buf_load4(xr, ro == OOB_OFF ? OOB_OFF : ro + xc * 16u, 0);   // no wrap past OOB_OFF
+      }
+#pragma unroll
+      for (int q = 0; q < YPX; ++q) {
+        const int m = c_begin + p0 + yg * YPX + q;
+        yreg[q] = buf_load4(yr, m < c_end ? ((unsigned)m * (unsigned)gCO + tj * BJ + yc * 4) * 4u : OOB_OFF, 0);
+      }
+    };
+    auto store_op = [&](unsigned* base, int plane_rows, const f32x4* reg, auto px_tag) {
+      constexpr int PX = decltype(px_tag)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // channel row 4c+e
+        unsigned* dst = base + e * LROW;
+        if constexpr (PX == 4) {
+          unsigned h0, m0, l0, h1, m1, l1;
+          split_pair(reg[0][e], reg[1][e], h0, m0, l0);
+          split_pair(reg[2][e], reg[3][e], h1, m1, l1);
+          *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+          *reinterpret_cast<u32x2*>(dst + plane_rows * LROW) = u32x2{m0, m1};
+          *reinterpret_cast<u32x2*>(dst + 2 * plane_rows * LROW) = u32x2{l0, l1};
+        } else {
+          unsigned h0, m0, l0;
+          split_pair(reg[0][e], reg[1][e], h0, m0, l0);
+          dst[0] = h0;
+          dst[plane_rows * LROW] = m0;
+          dst[2 * plane_rows * LROW] = l0;
+        }
+      }
+    };
+    auto store_tiles = [&](int buf) {
+      store_op(As + buf * ASZ + x_st, BI, xreg, std::integral_constant<int, XPX>{});
+      store_op(Bs + buf * BSZ + y_st, BJ, yreg, std::integral_constant<int, YPX>{});
+    };
+
+    const int nIter = (c_end - c_begin + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    if (nIter > 1) load_tiles(BK);
+    __syncthreads();
+    int it = 0;
+    for (; it + 2 < nIter; ++it) {   // branch-free steady state (see igemm_split_kernel)
+      const int cur = it & 1;
+      load_frags(cur, 0, f0);
+      load_frags(cur, 1, f1);
+      mma_frags(f0);
+      store_tiles(cur ^ 1);
+      load_tiles((it + 2) * BK);
+      mma_frags(f1);
+      __syncthreads();
+    }
+    if (it + 1 < nIter) {
+      const int cur = it & 1;
+      load_frags(cur, 0, f0);
+      load_frags(cur, 1, f1);
+      mma_frags(f0);
+      store_tiles(cur ^ 1);
+      mma_frags(f1);
+      __syncthreads();
+      ++it;
+    }
+    if (it < nIter) {
+      load_frags(it & 1, 0, f0);
+      load_frags(it & 1, 1, f1);
+      mma_frags(f0);
+      mma_frags(f1);
+    }
+  }
+
+  float* slab = part + ((size_t)blockIdx.y * g.T + t) * gC * gCO;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = ti * BI + wi * (BI / WI) + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = tj * BJ + wj * (BJ / WJ) + ni * 32 + i;
+        slab[(size_t)row * gCO + col] = acc[mi][ni][e];
+      }
+    }
+}
+
 // out[plane][t][n][k] (bf16): transposed = 1: n = co, k = ci (forward conv); 0: n = ci, k = co (input gradient).
 // in is HWIO fp32 [t][ci][co].
 __global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
@@ -369,4 +551,52 @@ extern "C" int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float
       if (int rc = launch_split(dy, wsplit, dx, residual, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
     }
   return MLA_OK;
+}
+
+// split-K plan of the split weight gradient: one 128x128 workgroup per CU (two 64x64), about two rounds of the chip
+static void wgrad_split_plan(long M, int Cin, int Cout, int T, int* span, int* splits) {
+  const int BI = (Cin % 128 == 0 && Cout % 128 == 0) ? 128 : 64;
+  const long tiles = (long)(Cin / BI) * T * (Cout / BI);
+  long want = (BI == 64 ? 1024 : 512) / tiles;
+  if (want < 1) want = 1;
+  long s = (M + want - 1) / want;
+  s = ((s + BK - 1) / BK) * BK;
+  if (s < 256) s = 256;
+  *span = (int)s;
+  *splits = (int)((M + s - 1) / s);
+}
+
+extern "C" size_t mla_conv2d_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
+  int span, splits;
+  wgrad_split_plan(M, Cin, Cout, KH * KW, &span, &splits);
+  return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
+}
+
+int mla_wgrad_reduce(const float* part, float* dw, size_t n4, int splits, hipStream_t st);   // conv_igemm.hip
+
+extern "C" int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                                      int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_conv("mla_conv2d_wgrad_split", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
+  MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_wgrad_split: Cin=%d must be a multiple of 64 (the stem runs on mla_conv2d_wgrad)", Cin);
+  MLA_REQUIRE(x && dy && dw && ws, "mla_conv2d_wgrad_split: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  IGemmGeom g;
+  make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  g.y_bytes = (unsigned)((size_t)g.M * Cout * 4);
+  int span, splits;
+  wgrad_split_plan(g.M, Cin, Cout, g.T, &span, &splits);
+  const size_t need = (size_t)splits * g.T * Cin * Cout * sizeof(float);
+  if (ws_bytes < need) {
+    mla_set_error("mla_conv2d_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
+    return MLA_ERR_WORKSPACE;
+  }
+  float* part = (float*)ws;
+  if (Cin % 128 == 0 && Cout % 128 == 0) {
+    wgrad_split_kernel<128, 128, 2, 2><<<dim3((Cin / 128) * (Cout / 128) * g.T, splits), 256, 0, st>>>(x, dy, part, g, span);
+  } else {
+    wgrad_split_kernel<64, 64, 2, 2><<<dim3((Cin / 64) * (Cout / 64) * g.T, splits), 256, 0, st>>>(x, dy, part, g, span);
+  }
+  MLA_CHECK_LAUNCH("wgrad_split_kernel");
+  return mla_wgrad_reduce(part, dw, (size_t)g.T * Cin * Cout / 4, splits, st);
 }

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "mla_conv2d_wsplit": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mla_conv2d_fwd_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
     "mla_conv2d_dgrad_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
+    "mla_conv2d_wgrad_split_ws_bytes": (_Z, [_I] * 9),
+    "mla_conv2d_wgrad_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
     "mla_conv2d_split_terms": (_I, [_I]),
     "mla_conv2d_split_cfg": (_I, [_I]),
     "mla_bn_partial_scratch_elems": (_Z, [_I]),

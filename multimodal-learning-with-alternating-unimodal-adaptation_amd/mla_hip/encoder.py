@@ -13,7 +13,7 @@ MI355X-first host design, not a module-by-module port:
   * conv_math selects the arithmetic of the forward / input-gradient contractions of the 64..512-channel convs:
     "f32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = fp32 operands split exactly into three bf16 terms,
     six products on v_mfma_f32_32x32x16_bf16 (fp32 in / out / accumulate, same error against fp64; the conv weights
-    are re-split once per forward).  The stem and the weight gradients always run on the fp32 MFMA.
+    are re-split once per forward).  The stem (1 / 3 input channels) always runs on the fp32 MFMA.
 """
 from __future__ import annotations
 
@@ -232,6 +232,8 @@ class ResNet18Encoder:
                         (((inpl, planes, 1, stride, 0, ch, cw),) if has_ds else ()):
                     max_partial = max(max_partial, ops.conv2d_fwd_partial_elems(N, hh, ww, ci, co, k, k, s, p))
                     max_wgrad = max(max_wgrad, ops.conv2d_wgrad_ws_bytes(N, hh, ww, ci, co, k, k, s, p))
+                    if self.conv_math == "split":
+                        max_wgrad = max(max_wgrad, ops.conv2d_wgrad_split_ws_bytes(N, hh, ww, ci, co, k, k, s, p))
                     max_w = max(max_w, ci * co * k * k)
                 max_bnws = max(max_bnws, ops.bn_bwd_ws_elems(N * oh * ow, planes))
                 ch, cw, inpl = oh, ow, planes
@@ -379,14 +381,15 @@ class ResNet18Encoder:
     def _wgrad(self, ws, x, dy, name, stride, pad) -> None:
         """Weight gradient of conv `name`; on the side stream when one is attached (after dy has been produced)."""
         side = self.wgrad_stream
+        wgrad = ops.conv2d_wgrad_split if name in self.wsp else ops.conv2d_wgrad
         if side is None:
-            ops.conv2d_wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
+            wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
             return
         ev = torch.cuda.Event()
         ev.record()                                   # dy is complete on the main stream at this point
         side.wait_event(ev)
         with torch.cuda.stream(side):
-            ops.conv2d_wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
+            wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
 
     def _dgrad(self, ws, st, dy, name, x_shape, stride, pad, dx, residual=None, relu_src=None) -> None:
         wsp = self.wsp.get(name)

@@ -210,6 +210,24 @@ def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, dw_hwio: torch.Tensor, strid
     return dw_hwio
 
 
+def conv2d_wgrad_split_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad) -> int:
+    return int(_lib.load().mla_conv2d_wgrad_split_ws_bytes(N, H, W, Cin, Cout, KH, KW, stride, pad))
+
+
+def conv2d_wgrad_split(x: torch.Tensor, dy: torch.Tensor, dw_hwio: torch.Tensor, stride: int, pad: int, ws: torch.Tensor,
+                       stream: Optional[int] = None) -> torch.Tensor:
+    """conv2d_wgrad on the split-bf16 MFMA path (Cin a multiple of 64); ws >= conv2d_wgrad_split_ws_bytes."""
+    N, H, W, Cin = x.shape
+    KH, KW, _, Cout = dw_hwio.shape
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_wgrad_split(_p(x), _p(dy), _p(dw_hwio), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                             _p(ws), ws.numel() * ws.element_size(), stream or cur_stream()),
+          "mla_conv2d_wgrad_split")
+    if t0 is not None:
+        TIMER.end("conv_wgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
+    return dw_hwio
+
+
 # ---- batch norm ---------------------------------------------------------------------------------
 def bn_stats_partial_elems(M: int, C: int) -> int:
     return int(_lib.load().mla_bn_stats_partial_elems(M, C))

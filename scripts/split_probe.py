@@ -45,6 +45,11 @@ for tag, N, H, W, Cin, Cout, k, s, p in shapes:
         dxr = torch.nn.grad.conv2d_input(xr.shape, wr, dyr, stride=s, padding=p).permute(0, 2, 3, 1)
         e_y32, e_dx32 = err(y32[:nb], yr), err(dx32[:nb], dxr)
         line += f" | err f32 y {e_y32[0]:.2e}/{e_y32[1]:.2e} dx {e_dx32[0]:.2e}/{e_dx32[1]:.2e}"
+    ws = torch.empty(max(ops.conv2d_wgrad_ws_bytes(N, H, W, Cin, Cout, k, k, s, p), ops.conv2d_wgrad_split_ws_bytes(N, H, W, Cin, Cout, k, k, s, p)) // 4 + 4, device="cuda")
+    dw32 = ops.conv2d_wgrad(x, dy, torch.empty_like(w), s, p, ws).clone()
+    dws = ops.conv2d_wgrad_split(x, dy, torch.empty_like(w), s, p, ws).clone()
+    t32 = timeit(lambda: ops.conv2d_wgrad(x, dy, dw32, s, p, ws)); tsp = timeit(lambda: ops.conv2d_wgrad_split(x, dy, dws, s, p, ws))
+    line += f" | wgrad f32 {gf/t32:6.1f} split {gf/tsp:6.1f} TF maxdiff {float((dws-dw32).abs().max()/dw32.abs().max()):.1e}"
     print(line, flush=True)
     for terms, cfg in [(t, c) for t in terms_list for c in cfgs]:
         if cfg >= 0 and Cout % (128 if cfg < 2 else 64) != 0: continue

@@ -133,6 +133,11 @@ def test_conv_split_fwd_dgrad(ops, case, cfg):
         assert_close(nchw(dx2.cpu()), (dx_ref + res) * (msk > 0), atol=0, rtol=2e-5, name="split dgrad+res+mask")
         ops.conv2d_dgrad_split(dyd, w_n, wd.shape, (N, H, W, Cin), s, p, dx=dx, residual=dx)
         assert_close(nchw(dx.cpu()), 2 * dx_ref, atol=0, rtol=2e-5, name="split dgrad accumulate")
+        if cfg == -1:   # the weight gradient has its own tiles (128x128 / 64x64)
+            dw_ref = O.conv2d_wgrad(x, dy, w.shape, s, p)
+            ws = torch.empty(ops.conv2d_wgrad_split_ws_bytes(N, H, W, Cin, Cout, k, k, s, p) // 4 + 4, device="cuda")
+            dw = ops.conv2d_wgrad_split(xd, dyd, torch.empty_like(wd), s, p, ws)
+            assert_close(oihw(dw.cpu()), dw_ref, atol=0, rtol=2e-5, name="split conv wgrad")
     finally:
         ops.conv2d_split_cfg(-1)
 

@@ -177,9 +177,12 @@ def test_adjoint_identities_full_size():
         # the split-bf16 forward / input-gradient kernels satisfy the same identities at the same sizes
         ys, _ = ops.conv2d_fwd_split(x, ops.conv2d_wsplit(w, True), w.shape, s, p)
         dxs = ops.conv2d_dgrad_split(dy, ops.conv2d_wsplit(w, False), w.shape, x.shape, s, p)
+        ws2 = torch.empty(ops.conv2d_wgrad_split_ws_bytes(N, H, W, Cin, Cout, k, k, s, p) // 4 + 4, device="cuda")
+        dws = ops.conv2d_wgrad_split(x, dy, torch.empty_like(w), s, p, ws2)
         a2 = (dy.double() * ys.double()).sum().item()
         b2 = (dxs.double() * x.double()).sum().item()
-        assert abs(a2 - b2) <= 1e-5 * scale and abs(a2 - a) <= 1e-5 * scale, (a, a2, b2, scale)
+        c2 = (dws.double() * w.double()).sum().item()
+        assert abs(a2 - b2) <= 1e-5 * scale and abs(a2 - a) <= 1e-5 * scale and abs(a2 - c2) <= 1e-5 * scale, (a, a2, b2, c2, scale)
 
 
 def test_loud_failure_without_gpu_library(monkeypatch):
