@@ -9,7 +9,9 @@ Workload (BASELINE.json configs[1]; configs[2] for N>1): CREMA-D, --gs_flag, Res
 per-GPU batch 64 of synthetic (1x1024x128 spectrogram + 3x3x224x224 frames), fp32, weak scaling.
 One "step" = joint encoder forward + 2 x {head fwd/CE/bwd, encoder backward, GS projection, SGD}.
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with
-`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM convolution, HIP events in a serialized pass after the timed region)
+`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM convolution, HIP events in a serialized pass after the timed region),
+`alt_math` (the same steps with the other conv arithmetic: --math f32 = exact fp32 MFMA, the default; split = exact
+3-way bf16 operand split, 6 bf16 MFMAs per fp32 product, fp32-equivalent accuracy; N=1 only)
 and `cpu_baseline` (the CPU oracle = "port" of the reference path, timed on this host's cores, N=1 only).
 """
 import argparse
@@ -25,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "multimodal-learning-with-alternating-unim
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_SPLIT_TFLOPS = 16 * 157.3 / 6  # conv_math=split: bf16 MFMA (16x the fp32 rate, ~2.5 PF dense), six products per fp32 product
 SPEC_HW, FRAMES, IMG_HW, N_CLASSES = (1024, 128), 3, (224, 224), 6
 
 
@@ -94,6 +97,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="disable the side-stream overlap (serialized kernels)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with the other conv arithmetic (N=1 only)")
     ap.add_argument("--math", choices=["f32", "split"], default=os.environ.get("MLA_CONV_MATH", "f32"),
                     help="conv forward/dgrad arithmetic: f32 = exact fp32 MFMA; split = exact 3-way bf16 operand split, "
                          "6 bf16 MFMAs per fp32 product (fp32-equivalent accuracy, see DESIGN.md)")
@@ -172,6 +176,25 @@ def main() -> None:
         dt = float(t.item())
     assert loss == loss, "loss is NaN"
 
+    alt = None
+    if world == 1 and not a.no_alt:
+        # the same K steps with the other conv arithmetic (fresh model, same seeds / inputs), after the main measurement
+        other = "split" if a.math == "f32" else "f32"
+        m2 = AVClassifier(Args(), device=dev, seed=1234, conv_math=other)
+        t2 = MLATrainer(m2, lr=1e-3, momentum=0.9, weight_decay=1e-4, gs_mode="as_intended", comm=comm)
+        if a.no_overlap:
+            t2.set_overlap(False)
+        for s in range(a.warmup):
+            t2.train_step(spec, image, label, s % len_dl, len_dl)
+        sync()
+        ta = time.perf_counter()
+        for s in range(a.steps):
+            t2.train_step(spec, image, label, (a.warmup + s) % len_dl, len_dl)
+        sync()
+        dta = time.perf_counter() - ta
+        alt = {"conv_math": other, "value": round(B * a.steps / dta, 2), "unit": "samples/s",
+               "ms_per_step": round(dta / a.steps * 1e3, 3), "final_loss": round(float(t2.losses["loss"].item()), 5)}
+        del t2, m2
     if rank == 0:
         summ = timer.summary()
         ig = {"ms": 0.0, "work": 0.0, "launches": 0}
@@ -179,9 +202,13 @@ def main() -> None:
             for f in ig:
                 ig[f] += summ.get(k, {}).get(f, 0)
         achieved = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        split = a.math == "split"
+        peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        kname = ("igemm_split_kernel (conv forward + input gradient, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; "
+                 "peak = bf16 MFMA rate / 6)") if split else "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)"
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
-        if os.path.exists(tpath):     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, per launch
+        if os.path.exists(tpath) and not split:     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, per launch
             tj = json.load(open(tpath))
             traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/r01_igemm_traffic.json: " + tj["method"]
         per_kind = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
@@ -194,9 +221,9 @@ def main() -> None:
             "config": {"workload": "CREMA-D MLA step (--gs_flag, --lorb base ResNet18 audio+visual, GS projection as_intended), "
                                    "per-GPU batch %d: spec 1x1024x128 + frames 3x3x224x224, 6 classes" % B,
                        "global_batch": B * world, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "avg_launch_ms": round(ig["ms"] / max(ig["launches"], 1), 4),
                          "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2),
                          "measured": "HIP events around every conv launch over %d steps run right after the timed region "
@@ -208,6 +235,8 @@ def main() -> None:
             "kernels": per_kind,
             "final_loss": round(loss, 5),
         }
+        if alt is not None:
+            out["alt_math"] = alt
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

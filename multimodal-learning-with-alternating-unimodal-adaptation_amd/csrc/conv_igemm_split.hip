@@ -20,9 +20,6 @@
 // sits at chunk slot q ^ ((r >> 2) & 3), which makes the MFMA fragment reads (ds_read_b128, 16-lane groups
 // {0-3,12-15,20-27}, ...) and the staging stores conflict-free.
 #define LROW 16
-#ifndef ABL
-#define ABL 0   // timing-only ablations (1: no split arithmetic, 3: no staging, 4: no MFMA); results are wrong unless 0
-#endif
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -149,13 +146,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
       unsigned h0, m0, l0, h1, m1, l1;
-#if ABL == 1
-      h0 = m0 = l0 = __float_as_uint(areg[p][0]) ^ __float_as_uint(areg[p][1]);
-      h1 = m1 = l1 = __float_as_uint(areg[p][2]) ^ __float_as_uint(areg[p][3]);
-#else
       split_pair(areg[p][0], areg[p][1], h0, m0, l0);
       split_pair(areg[p][2], areg[p][3], h1, m1, l1);
-#endif
       unsigned* dst = Ad + p * AROWS * LROW;
       *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
       *reinterpret_cast<u32x2*>(dst + BM * LROW) = u32x2{m0, m1};
@@ -202,23 +194,21 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
   }
   __syncthreads();
   // Steady state is branch-free so the scheduler can interleave the staging work with the MFMAs; the last two
-  // K steps (nothing left to load / to stage) are peeled.  Measured alternative: a second register set with the
-  // loads of tile it+2 pinned at the top of step it (a full K step of latency cover) is 3-7 % slower.
+  // K steps (nothing left to load / to stage) are peeled.  Measured alternatives (l2 shape, 128x128 tile, 177 TF):
+  // a second register set with the loads of tile it+2 pinned at the top of step it: 3-7 % slower; a ring of three
+  // LDS buffers with the next step's first-half fragments fetched before the barrier: +-0.  Timing-only ablations:
+  // MFMAs alone reach the 6-product ceiling (333 TF at the sustained bf16 rate) once the tail of the last round is
+  // taken out; adding the fragment reads costs ~20 %, the barrier nothing, staging another ~17 %; a tile's
+  // prologue / epilogue are exposed (one workgroup per CU), which is what holds the K = 576 layers at ~140 TF.
   int it = 0;
   for (; it + 2 < nIter; ++it) {
     const int cur = it & 1;
     load_frags(cur, 0, f0);
     load_frags(cur, 1, f1);   // both halves' fragments in flight before the first MFMA
-#if ABL != 4
     mma_frags(f0);
-#endif
-#if ABL != 3
     store_tiles(cur ^ 1);   // readers of that buffer finished before the previous barrier
     load_tiles(it + 2);
-#endif
-#if ABL != 4
     mma_frags(f1);
-#endif
     __syncthreads();
   }
   if (it + 1 < nIter) {
