@@ -76,6 +76,10 @@ int mla_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio,
  * measurements; 6 is the default and the only set the parity tests bless. */
 size_t mla_conv2d_wsplit_bytes(int Cin, int Cout, int KH, int KW);
 int mla_conv2d_wsplit(const float* w_hwio, void* wsplit, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
+/* Batched form (one launch for all convs of a flat parameter buffer).  desc: n <= 64 rows of 8 ints in DEVICE memory,
+ * {w_off (floats from params), out_off (16-bit elements from wsplit), taps, Cin, Cout, transposed, first_block, 0} with
+ * first_block the running sum of taps*ceil(Cin/32)*ceil(Cout/32); total_blocks = that sum over all rows. */
+int mla_conv2d_wsplit_batch(const float* params, void* wsplit, const int* desc, int n, int total_blocks, void* stream);
 int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float* y,
                          int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                          float* bn_partial, int* bn_tiles, void* stream);

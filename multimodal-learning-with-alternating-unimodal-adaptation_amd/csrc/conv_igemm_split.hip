@@ -196,7 +196,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
   // Steady state is branch-free so the scheduler can interleave the staging work with the MFMAs; the last two
   // K steps (nothing left to load / to stage) are peeled.  Measured alternatives (l2 shape, 128x128 tile, 177 TF):
   // a second register set with the loads of tile it+2 pinned at the top of step it: 3-7 % slower; a ring of three
-  // LDS buffers with the next step's first-half fragments fetched before the barrier: +-0.  Timing-only ablations:
+  // LDS buffers with the next step's first-half fragments fetched before the barrier: +-0; plane-wise fragment reads
+  // issued one MFMA group ahead of their use, with and without sched_group_barrier pinning: +-1 %.  Timing-only ablations:
   // MFMAs alone reach the 6-product ceiling (333 TF at the sustained bf16 rate) once the tail of the last round is
   // taken out; adding the fragment reads costs ~20 %, the barrier nothing, staging another ~17 %; a tile's
   // prologue / epilogue are exposed (one workgroup per CU), which is what holds the K = 576 layers at ~140 TF.
@@ -413,12 +414,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(const float* __rest
 }
 
 // out[plane][t][n][k] (bf16): transposed = 1: n = co, k = ci (forward conv); 0: n = ci, k = co (input gradient).
-// in is HWIO fp32 [t][ci][co].
-__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
-                                                            int T, int CI, int CO, int transposed) {
-  __shared__ float tile[32][33];
-  const int t = blockIdx.z;
-  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+// in is HWIO fp32 [t][ci][co].  One 32x32 (ci x co) tile of one tap per workgroup.
+__device__ __forceinline__ void weight_split_tile(const float* __restrict__ in, unsigned short* __restrict__ out, int T, int CI,
+                                                  int CO, int transposed, int t, int ci0, int co0, float (*tile)[33]) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
   const size_t plane = (size_t)T * CI * CO;
   for (int r = ty; r < 32; r += 8) {
@@ -440,6 +438,29 @@ __global__ __launch_bounds__(256) void weight_split_kernel(const float* __restri
       out[2 * plane + o] = (unsigned short)lo;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
+                                                            int T, int CI, int CO, int transposed) {
+  __shared__ float tile[32][33];
+  weight_split_tile(in, out, T, CI, CO, transposed, blockIdx.z, blockIdx.y * 32, blockIdx.x * 32, tile);
+}
+
+// Every conv of an encoder in one launch: desc[j] = {w_off, out_off, T, CI, CO, transposed, first_block, -} (device memory)
+__global__ __launch_bounds__(256) void weight_split_batch_kernel(const float* __restrict__ params, unsigned short* __restrict__ out,
+                                                                  const int* __restrict__ desc, int n) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < n && desc[(j + 1) * 8 + 6] <= b) ++j;   // n <= 64: a short scalar scan
+  const int* d = desc + j * 8;
+  const int T = d[2], CI = d[3], CO = d[4];
+  const int tc = (CO + 31) / 32, tr = (CI + 31) / 32;
+  int lb = b - d[6];
+  const int bx = lb % tc; lb /= tc;
+  const int by = lb % tr; lb /= tr;
+  if (lb >= T) return;
+  weight_split_tile(params + d[0], out + d[1], T, CI, CO, d[5], lb, by * 32, bx * 32, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -510,6 +531,14 @@ extern "C" int mla_conv2d_wsplit(const float* w, void* wsplit, int Cin, int Cout
   weight_split_kernel<<<dim3(cdiv(Cout, 32), cdiv(Cin, 32), KH * KW), 256, 0, (hipStream_t)stream>>>(
       w, (unsigned short*)wsplit, KH * KW, Cin, Cout, transposed ? 1 : 0);
   MLA_CHECK_LAUNCH("weight_split_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_conv2d_wsplit_batch(const float* params, void* wsplit, const int* desc, int n, int total_blocks, void* stream) {
+  MLA_REQUIRE(params && wsplit && desc, "mla_conv2d_wsplit_batch: null pointer");
+  MLA_REQUIRE(n > 0 && n <= 64 && total_blocks > 0, "mla_conv2d_wsplit_batch: n=%d (1..64), total_blocks=%d", n, total_blocks);
+  weight_split_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(params, (unsigned short*)wsplit, desc, n);
+  MLA_CHECK_LAUNCH("weight_split_batch_kernel");
   return MLA_OK;
 }
 

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "mla_conv2d_wgrad": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
     "mla_conv2d_wsplit_bytes": (_Z, [_I] * 4),
     "mla_conv2d_wsplit": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mla_conv2d_wsplit_batch": (_I, [_P, _P, _P, _I, _I, _P]),
     "mla_conv2d_fwd_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
     "mla_conv2d_dgrad_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
     "mla_conv2d_wgrad_split_ws_bytes": (_Z, [_I] * 9),

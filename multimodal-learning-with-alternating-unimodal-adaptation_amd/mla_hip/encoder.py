@@ -113,13 +113,19 @@ class ResNet18Encoder:
         if self.conv_math == "split":
             tot16 = sum(2 * 3 * k * k * cin * cout for _n, cin, cout, k, _s, _p in self.specs if cin % 64 == 0)
             self._wsplit_flat = torch.empty(tot16, device=self.device, dtype=torch.int16)
-            o16 = 0
+            o16, rows, blocks = 0, [], 0
             for name, cin, cout, k, _s, _p in self.specs:
                 if cin % 64 != 0:
                     continue
                 n16 = 3 * k * k * cin * cout
                 self.wsp[name] = (self._wsplit_flat[o16:o16 + n16], self._wsplit_flat[o16 + n16:o16 + 2 * n16])
+                nb = k * k * ((cin + 31) // 32) * ((cout + 31) // 32)
+                for transposed, off in ((1, o16), (0, o16 + n16)):     # descriptor rows of mla_conv2d_wsplit_batch
+                    rows.append([self.layout[name + ".weight"][0], off, k * k, cin, cout, transposed, blocks, 0])
+                    blocks += nb
                 o16 += 2 * n16
+            self._wsplit_desc = torch.tensor(rows, dtype=torch.int32, device=self.device)
+            self._wsplit_blocks = blocks
         # Optional second HIP stream for the weight-gradient GEMMs: they are off the dgrad -> BN-backward critical
         # chain, so (with one dy buffer per conv: 288 GB of HBM) they run beside it and fill its kernel tails.
         self.wgrad_stream: Optional[torch.cuda.Stream] = None
@@ -269,10 +275,7 @@ class ResNet18Encoder:
     # ------------------------------------------------------------------------------------------
     def _refresh_wsplit(self, st) -> None:
         """Re-split the conv weights (they change with every optimizer step; in eval mode only when marked dirty)."""
-        for name, (w_fwd, w_dgrad) in self.wsp.items():
-            w = self.p[name + ".weight"]
-            ops.conv2d_wsplit(w, True, out=w_fwd, stream=st)
-            ops.conv2d_wsplit(w, False, out=w_dgrad, stream=st)
+        ops.conv2d_wsplit_batch(self.flat, self._wsplit_flat, self._wsplit_desc, self._wsplit_blocks, stream=st)
         self._wsplit_dirty = False
 
     def train(self, mode: bool = True):

@@ -146,6 +146,13 @@ def conv2d_wsplit(w_hwio: torch.Tensor, transposed: bool, out: Optional[torch.Te
     return out
 
 
+def conv2d_wsplit_batch(params: torch.Tensor, wsplit: torch.Tensor, desc: torch.Tensor, total_blocks: int,
+                        stream: Optional[int] = None) -> None:
+    """One launch that re-splits every conv listed in `desc` (int32 device tensor, n x 8; see include/mla_hip.h)."""
+    check(_lib.load().mla_conv2d_wsplit_batch(_p(params), _p(wsplit, torch.int16), _p(desc, torch.int32), desc.shape[0],
+                                              int(total_blocks), stream or cur_stream()), "mla_conv2d_wsplit_batch")
+
+
 def conv2d_fwd_split(x: torch.Tensor, wsplit_t: torch.Tensor, w_shape, stride: int, pad: int,
                      y: Optional[torch.Tensor] = None, bn_partial: Optional[torch.Tensor] = None,
                      stream: Optional[int] = None) -> Tuple[torch.Tensor, int]:

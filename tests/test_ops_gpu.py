@@ -142,6 +142,20 @@ def test_conv_split_fwd_dgrad(ops, case, cfg):
         ops.conv2d_split_cfg(-1)
 
 
+def test_wsplit_batch_matches_per_conv(ops):
+    """The one-launch weight split of an encoder equals the per-conv entry point, both orientations, bit for bit,
+    and hi + mid + lo reproduces the fp32 weights exactly."""
+    from mla_hip.encoder import ResNet18Encoder
+    enc = ResNet18Encoder("visual", "cuda", seed=3, conv_math="split")
+    enc._refresh_wsplit(ops.cur_stream())
+    for name, (w_fwd, w_dgrad) in enc.wsp.items():
+        w = enc.p[name + ".weight"]
+        assert torch.equal(w_fwd, ops.conv2d_wsplit(w, True)), name
+        assert torch.equal(w_dgrad, ops.conv2d_wsplit(w, False)), name
+        planes = w_dgrad.view(3, *w.shape).view(torch.bfloat16).float()
+        assert torch.equal(planes.sum(0), w), name          # exact 3-way split (sum of three bf16 values in fp32)
+
+
 def test_conv_split_is_not_reduced_precision(ops):
     """The claim behind conv_math="split": against an fp64 reference the six-product bf16 split is at least as
     accurate as the exact-fp32 MFMA kernel (same inputs, K = 576 .. 4608), element-wise maximum and rms.  The
