@@ -92,7 +92,7 @@ int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw_hwio,
                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            void* ws, size_t ws_bytes, void* stream);
 int mla_conv2d_split_terms(int terms);
-/* measurement hook: force tile 0..3 (256x128, 128x128, 128x64, 64x64) where Cout allows; -1 = automatic */
+/* measurement hook: force tile 0..4 (256x128, 128x128, 128x64, 64x64, 256x64) where Cout allows; -1 = automatic */
 int mla_conv2d_split_cfg(int cfg);
 
 /* ---- BatchNorm2d, training mode (backbone.py:29, 32, 86, 128) -------------------------------- */

@@ -20,6 +20,9 @@
 // sits at chunk slot q ^ ((r >> 2) & 3), which makes the MFMA fragment reads (ds_read_b128, 16-lane groups
 // {0-3,12-15,20-27}, ...) and the staging stores conflict-free.
 #define LROW 16
+#ifndef SPLIT_EFF
+#define SPLIT_EFF 1.0, 0.95, 0.8, 0.7, 0.9
+#endif
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -54,17 +57,27 @@ __device__ constexpr int TERM_B[8] = {0, 1, 0, 1, 2, 0, 2, 1};
 // read buffer it&1, the same waves split the register-staged tile it+1 into the other buffer and issue the global
 // loads of tile it+2.  (Two co-resident workgroups with a single buffer each fall into lock step -- both in the
 // MFMA phase, then both in the staging phase -- and the phases add instead of overlapping; measured.)
-template <int BM, int BN, int WM, int WN, int TERMS>
-__global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const float* __restrict__ X, const void* __restrict__ Wsp,
-                                                                       float* Y, const float* R, const float* MASK,
-                                                                       float* __restrict__ part, const float* __restrict__ BIAS,
-                                                                       float* __restrict__ Y2, const IGemmGeom g) {
+// BKS = K per stage: 32 (64-B LDS rows, two MFMA k-chunks per barrier) or 16 (32-B rows, one k-chunk per barrier, half
+// the LDS: two 8-wave workgroups per CU, whose prologues / epilogues / barriers then overlap each other).
+// Chunk swizzle of row r: BKS 32: 16-B chunk q -> q ^ ((r >> 2) & 3);  BKS 16: 16-B half q -> q ^ ((r >> 3) & 1).
+template <int BM, int BN, int WM, int WN, int TERMS, int BKS, int WPE>
+__global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const float* __restrict__ X, const void* __restrict__ Wsp,
+                                                                         float* Y, const float* R, const float* MASK,
+                                                                         float* __restrict__ part, const float* __restrict__ BIAS,
+                                                                         float* __restrict__ Y2, const IGemmGeom g) {
+  static_assert(BKS == 32 || BKS == 16, "stage depth");
   constexpr int NT = 64 * WM * WN;
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-  constexpr int AROWS = NT / 8, APASS = BM / AROWS;   // A: 8 float4 per row and K step
-  constexpr int BROWS = NT / 4, BPASS = BN / BROWS;   // B: 4 x 16 B per row, plane and K step
-  static_assert(APASS >= 1 && BPASS >= 1 && AROWS % 16 == 0, "tile too small for the workgroup");
-  constexpr int ASZ = 3 * BM * LROW, BSZ = 3 * BN * LROW;   // dwords per buffer
+  constexpr int LR = BKS / 2;                                  // dwords per LDS row
+  constexpr int ACH = BKS / 4;                                 // float4 chunks per A row and stage
+  constexpr int AROWS = NT / ACH, APASS = BM / AROWS;
+  constexpr int BROWS = NT / 4;                                // B: 4 chunks of BKS/2 bytes per row, plane and stage
+  constexpr int BPASS = (BN + BROWS - 1) / BROWS;
+  constexpr bool BPART = BN < BROWS;                           // only the first BN*4 threads stage B
+  constexpr int NKK = BKS / 16;                                // MFMA k-chunks per stage
+  static_assert(APASS >= 1 && AROWS % 16 == 0 && (BN % BROWS == 0 || BPART), "tile / workgroup mismatch");
+  constexpr int ASZ = 3 * BM * LR, BSZ = 3 * BN * LR;          // dwords per buffer
+  typedef typename std::conditional<BKS == 32, u32x4, u32x2>::type bchunk_t;
 
   __shared__ __attribute__((aligned(16))) unsigned As[2 * ASZ];
   __shared__ __attribute__((aligned(16))) unsigned Bs[2 * BSZ];
@@ -101,18 +114,21 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  const int cpt = gC / BK;          // K steps per tap
+  const int cpt = gC / BKS;         // stages per tap
   const int nIter = g.T * cpt;
   const unsigned plane_bytes = g.w_bytes / 2;   // one bf16 plane of the whole weight tensor
 
   f32x4 areg[APASS];
-  u32x4 breg[3][BPASS];
+  bchunk_t breg[3][BPASS];
   const rsrc_t xr = make_rsrc(X, g.x_bytes), wr = make_rsrc(Wsp, 3 * plane_bytes);
+  const int arow = tid / ACH, ac = tid % ACH;       // A: row within a pass, float4 chunk
+  const int brow = tid >> 2, bq = tid & 3;          // B: row within a pass, chunk
+  const bool bact = !BPART || tid < BN * 4;         // wave-uniform (BN*4 is a multiple of 64)
   unsigned rowoff[APASS], tmask[APASS], boff[BPASS];
 #pragma unroll
   for (int p = 0; p < APASS; ++p) {
-    const int4 info = rowinfo[p * AROWS + (tid >> 3)];
-    rowoff[p] = ((unsigned)(info.x + info.y * gW + info.z) * (unsigned)gC + (tid & 7) * 4) * 4u;
+    const int4 info = rowinfo[p * AROWS + arow];
+    rowoff[p] = ((unsigned)(info.x + info.y * gW + info.z) * (unsigned)gC + ac * 4) * 4u;
     unsigned m = 0;
     for (int t = 0; t < g.T; ++t) {
       const int tp = g.tap[t];
@@ -122,24 +138,31 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
     tmask[p] = m;
   }
 #pragma unroll
-  for (int p = 0; p < BPASS; ++p) boff[p] = ((unsigned)(p * BROWS + (tid >> 2)) * (unsigned)gC + (tid & 3) * 8) * 2u;
+  for (int p = 0; p < BPASS; ++p) boff[p] = ((unsigned)(p * BROWS + brow) * (unsigned)gC + bq * (BKS / 4)) * 2u;
 
   auto load_tiles = [&](int it) {
-    const int t = it / cpt, c0 = (it - t * cpt) * BK;
+    const int t = it / cpt, c0 = (it - t * cpt) * BKS;
     const int tp = g.tap[t];
     const unsigned toff = (unsigned)(((tap_dy(tp) * gW + tap_dx(tp)) * gC + c0) * 4);       // wave-uniform (SGPR)
 #pragma unroll
     for (int p = 0; p < APASS; ++p)
       areg[p] = buf_load4(xr, ((tmask[p] >> t) & 1u) ? rowoff[p] + toff : OOB_OFF, 0);
     const unsigned wsoff = (unsigned)(((tap_wt(tp) * gCO + tn * BN) * gC + c0) * 2);        // wave-uniform
+    if (bact) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int p = 0; p < BPASS; ++p) breg[pl][p] = buf_load4u(wr, boff[p], wsoff + pl * plane_bytes);
+        for (int p = 0; p < BPASS; ++p) {
+          if constexpr (BKS == 32) breg[pl][p] = buf_load4u(wr, boff[p], wsoff + pl * plane_bytes);
+          else breg[pl][p] = __builtin_amdgcn_raw_buffer_load_b64(wr, (int)boff[p], (int)(wsoff + pl * plane_bytes), 0);
+        }
+    }
   };
-  // staging stores: thread (row = tid>>3, c = tid&7) owns k = 4c..4c+3 of its A rows, (n = tid>>2, q = tid&3) chunk q of its B rows
-  const int a_st = (tid >> 3) * LROW + ((((tid & 7) >> 1) ^ ((tid >> 5) & 3)) << 2) + (tid & 1) * 2;
-  const int b_st = (tid >> 2) * LROW + (((tid & 3) ^ ((tid >> 4) & 3)) << 2);
+  // staging stores: A thread (row, c) owns k = 4c..4c+3 (8 B per plane); B thread (row, q) owns chunk q (BKS/2 bytes)
+  const int a_st = BKS == 32 ? arow * LR + ((((ac >> 1) ^ ((arow >> 2) & 3)) << 2) + (ac & 1) * 2)
+                             : arow * LR + ((((ac >> 1) ^ ((arow >> 3) & 1)) << 2) + (ac & 1) * 2);
+  const int b_st = BKS == 32 ? brow * LR + ((bq ^ ((brow >> 2) & 3)) << 2)
+                             : brow * LR + ((((bq >> 1) ^ ((brow >> 3) & 1)) << 2) + (bq & 1) * 2);
   auto store_tiles = [&](int buf) {
     unsigned* Ad = As + buf * ASZ + a_st;
     unsigned* Bd = Bs + buf * BSZ + b_st;
@@ -148,20 +171,23 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
       unsigned h0, m0, l0, h1, m1, l1;
       split_pair(areg[p][0], areg[p][1], h0, m0, l0);
       split_pair(areg[p][2], areg[p][3], h1, m1, l1);
-      unsigned* dst = Ad + p * AROWS * LROW;
+      unsigned* dst = Ad + p * AROWS * LR;
       *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(dst + BM * LROW) = u32x2{m0, m1};
-      *reinterpret_cast<u32x2*>(dst + 2 * BM * LROW) = u32x2{l0, l1};
+      *reinterpret_cast<u32x2*>(dst + BM * LR) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(dst + 2 * BM * LR) = u32x2{l0, l1};
     }
+    if (bact) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int p = 0; p < BPASS; ++p)
-        *reinterpret_cast<u32x4*>(Bd + (pl * BN + p * BROWS) * LROW) = breg[pl][p];
+        for (int p = 0; p < BPASS; ++p)
+          *reinterpret_cast<bchunk_t*>(Bd + (pl * BN + p * BROWS) * LR) = breg[pl][p];
+    }
   };
 
-  const int i = lane & 31, h = lane >> 5, swz = (i >> 2) & 3;
-  const int a_rd = (wm * (BM / WM) + i) * LROW, b_rd = (wn * (BN / WN) + i) * LROW;
+  const int i = lane & 31, h = lane >> 5;
+  const int swz = BKS == 32 ? (i >> 2) & 3 : (i >> 3) & 1;
+  const int a_rd = (wm * (BM / WM) + i) * LR, b_rd = (wn * (BN / WN) + i) * LR;
   struct Frags { bf16x8_t a[3][MI], b[3][NI]; };
   auto load_frags = [&](int buf, int kk, Frags& f) {   // lane (i, h) holds k = kk*16 + 8h .. +7 of row / column i
     const unsigned* Ar = As + buf * ASZ + a_rd + (((kk * 2 + h) ^ swz) << 2);
@@ -170,10 +196,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        f.a[pl][mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ar + (pl * BM + mi * 32) * LROW));
+        f.a[pl][mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ar + (pl * BM + mi * 32) * LR));
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        f.b[pl][ni] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Br + (pl * BN + ni * 32) * LROW));
+        f.b[pl][ni] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Br + (pl * BN + ni * 32) * LR));
     }
   };
   auto mma_frags = [&](const Frags& f) {
@@ -194,39 +220,39 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void igemm_split_kernel(const floa
   }
   __syncthreads();
   // Steady state is branch-free so the scheduler can interleave the staging work with the MFMAs; the last two
-  // K steps (nothing left to load / to stage) are peeled.  Measured alternatives (l2 shape, 128x128 tile, 177 TF):
+  // stages (nothing left to load / to stage) are peeled.  Measured alternatives (l2 shape, 128x128 tile, 177 TF):
   // a second register set with the loads of tile it+2 pinned at the top of step it: 3-7 % slower; a ring of three
   // LDS buffers with the next step's first-half fragments fetched before the barrier: +-0; plane-wise fragment reads
   // issued one MFMA group ahead of their use, with and without sched_group_barrier pinning: +-1 %.  Timing-only ablations:
   // MFMAs alone reach the 6-product ceiling (333 TF at the sustained bf16 rate) once the tail of the last round is
   // taken out; adding the fragment reads costs ~20 %, the barrier nothing, staging another ~17 %; a tile's
-  // prologue / epilogue are exposed (one workgroup per CU), which is what holds the K = 576 layers at ~140 TF.
+  // prologue / epilogue are exposed with one workgroup per CU (~10 us per tile round on the 1x1 convs).
   int it = 0;
   for (; it + 2 < nIter; ++it) {
     const int cur = it & 1;
     load_frags(cur, 0, f0);
-    load_frags(cur, 1, f1);   // both halves' fragments in flight before the first MFMA
+    if constexpr (NKK == 2) load_frags(cur, 1, f1);   // both halves' fragments in flight before the first MFMA
     mma_frags(f0);
     store_tiles(cur ^ 1);   // readers of that buffer finished before the previous barrier
     load_tiles(it + 2);
-    mma_frags(f1);
+    if constexpr (NKK == 2) mma_frags(f1);
     __syncthreads();
   }
   if (it + 1 < nIter) {
     const int cur = it & 1;
     load_frags(cur, 0, f0);
-    load_frags(cur, 1, f1);
+    if constexpr (NKK == 2) load_frags(cur, 1, f1);
     mma_frags(f0);
     store_tiles(cur ^ 1);
-    mma_frags(f1);
+    if constexpr (NKK == 2) mma_frags(f1);
     __syncthreads();
     ++it;
   }
   if (it < nIter) {
     load_frags(it & 1, 0, f0);
-    load_frags(it & 1, 1, f1);
+    if constexpr (NKK == 2) load_frags(it & 1, 1, f1);
     mma_frags(f0);
-    mma_frags(f1);
+    if constexpr (NKK == 2) mma_frags(f1);
     __syncthreads();
   }
   igemm_epilogue<BM, BN, WM, WN>(acc, rowinfo, reinterpret_cast<float*>(As), Y, R, MASK, part, BIAS, Y2, g, tm, tn);
@@ -472,26 +498,29 @@ extern "C" int mla_conv2d_split_terms(int terms) {   // measurement hook: 3, 6 (
   return g_split_terms;
 }
 
-// Tiles: 256x128 and 128x128 on 8 waves, 128x64 and 64x64 on 4 waves.
-enum { SCFG_256x128 = 0, SCFG_128x128 = 1, SCFG_128x64 = 2, SCFG_64x64 = 3, SCFG_COUNT = 4 };
-static int scfg_bm(int c) { return c == SCFG_256x128 ? 256 : (c == SCFG_64x64 ? 64 : 128); }
+// Tiles: 256x128 and 128x128 (8 waves, K stage 32, one workgroup per CU), 256x64 (8 waves, K stage 16, two per CU:
+// the Cout = 64 layers, +10 % over 128x64), 128x64 and 64x64 (4 waves, K stage 32, two / three per CU).  Measured the other
+// way round too: 128x128 at K stage 16 with two workgroups per CU is 6-15 % slower than one at K stage 32, 256x64 at
+// K stage 32 (one per CU) 5-15 % slower than two at K stage 16.
+enum { SCFG_256x128 = 0, SCFG_128x128 = 1, SCFG_128x64 = 2, SCFG_64x64 = 3, SCFG_256x64 = 4, SCFG_COUNT = 5 };
+static int scfg_bm(int c) { return (c == SCFG_256x128 || c == SCFG_256x64) ? 256 : (c == SCFG_64x64 ? 64 : 128); }
 static int scfg_bn(int c) { return c <= SCFG_128x128 ? 128 : 64; }
 static int g_split_cfg = -1;   // measurement hook: force one tile
 extern "C" int mla_conv2d_split_cfg(int cfg) { g_split_cfg = (cfg >= 0 && cfg < SCFG_COUNT) ? cfg : -1; return g_split_cfg; }
 
-// Minimise rounds * resident workgroups * tile area / efficiency.  The double-buffered LDS images leave room for one
-// 8-wave workgroup per CU (2 of the 128x64, 3 of the 64x64 tile); small tiles stage more bytes per MFMA.  The
+// Minimise rounds * resident workgroups * tile area / efficiency.  Small tiles stage more bytes per MFMA.  The
 // efficiencies are the measured per-flop rates at the ResNet-18 layer shapes relative to the 256x128 tile
 // (scripts/split_probe.py); the ranking they give matches the measured ranking on l1..l4 of both modalities.
 static int pick_scfg(long M, int CO, int weight) {
   if (g_split_cfg >= 0 && CO % scfg_bn(g_split_cfg) == 0) return g_split_cfg;
-  const double eff[SCFG_COUNT] = {1.0, 0.95, 0.8, 0.7};
+  const double eff[SCFG_COUNT] = {SPLIT_EFF};
+  const int per_cu_tab[SCFG_COUNT] = {1, 1, 2, 3, 2};            // resident workgroups per CU (LDS / VGPRs)
   int best = -1;
   double best_cost = 0;
   for (int c = 0; c < SCFG_COUNT; ++c) {
     if (CO % scfg_bn(c) != 0) continue;
     const double blocks = (double)cdiv(M, scfg_bm(c)) * (CO / scfg_bn(c));
-    const int per_cu = c == SCFG_64x64 ? 3 : (c == SCFG_128x64 ? 2 : 1);    // resident workgroups per CU (LDS)
+    const int per_cu = per_cu_tab[c];
     const double rounds = (double)((long)((blocks + 256 * per_cu - 1) / (256 * per_cu)));
     const double cost = rounds * per_cu * scfg_bm(c) * scfg_bn(c) / eff[c];
     if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
@@ -503,10 +532,11 @@ static int pick_scfg(long M, int CO, int weight) {
 template <int TERMS>
 static void launch_split_t(int cfg, int total, hipStream_t st, const float* X, const void* Wsp, float* Y, const float* R,
                            const float* MASK, float* part, const float* BIAS, float* Y2, const IGemmGeom& mg) {
-  if (cfg == SCFG_256x128) igemm_split_kernel<256, 128, 4, 2, TERMS><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
-  else if (cfg == SCFG_128x128) igemm_split_kernel<128, 128, 2, 4, TERMS><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
-  else if (cfg == SCFG_128x64) igemm_split_kernel<128, 64, 2, 2, TERMS><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
-  else igemm_split_kernel<64, 64, 2, 2, TERMS><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  if (cfg == SCFG_256x128) igemm_split_kernel<256, 128, 4, 2, TERMS, 32, 1><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else if (cfg == SCFG_128x128) igemm_split_kernel<128, 128, 2, 4, TERMS, 32, 1><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else if (cfg == SCFG_256x64) igemm_split_kernel<256, 64, 4, 2, TERMS, 16, 4><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else if (cfg == SCFG_128x64) igemm_split_kernel<128, 64, 2, 2, TERMS, 32, 1><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else igemm_split_kernel<64, 64, 2, 2, TERMS, 32, 1><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
 }
 
 static int launch_split(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part,

@@ -52,7 +52,7 @@ for tag, N, H, W, Cin, Cout, k, s, p in shapes:
     line += f" | wgrad f32 {gf/t32:6.1f} split {gf/tsp:6.1f} TF maxdiff {float((dws-dw32).abs().max()/dw32.abs().max()):.1e}"
     print(line, flush=True)
     for terms, cfg in [(t, c) for t in terms_list for c in cfgs]:
-        if cfg >= 0 and Cout % (128 if cfg < 2 else 64) != 0: continue
+        if cfg >= 0 and Cout % (128 if cfg in (0, 1) else 64) != 0: continue
         ops.conv2d_split_terms(terms); ops.conv2d_split_cfg(cfg)
         ys, _ = ops.conv2d_fwd_split(x, wsT, w.shape, s, p)
         dxs = ops.conv2d_dgrad_split(dy, wsN, w.shape, x.shape, s, p)

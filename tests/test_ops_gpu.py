@@ -101,11 +101,11 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
 SPLIT_CASES = [c for c in CONV_CASES if c[3] % 64 == 0] + [(2, 33, 17, 128, 128, 3, 1, 1)]   # M = 1122: ragged vs every tile
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3], ids=lambda c: f"tile{c}")
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4], ids=lambda c: f"tile{c}")
 @pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_split_fwd_dgrad(ops, case, cfg):
     """Split-bf16 arithmetic (6 bf16 products per fp32 product): same parity bar as the fp32-MFMA kernels
-    (2e-5 of max|ref|), every tile configuration (256x128 / 128x128 on 8 waves, 128x64 / 64x64 on 4 waves)."""
+    (2e-5 of max|ref|), every tile configuration (256x128 / 128x128 / 256x64 on 8 waves, 128x64 / 64x64 on 4 waves; K stage 32 or 16)."""
     N, H, W, Cin, Cout, k, s, p = case
     seed = sum(case)
     x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
