@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
 
   // Single LDS buffer + register prefetch, two barriers per K step.  Measured alternatives (a.l2/a.l3/a.l4
   // shapes, same run): double-buffered LDS with one barrier per step -2 % (70 KB LDS -> 2 instead of 3
-  // resident workgroups); staggering co-resident workgroups +-0 %.  Timing-only ablations put the ceiling of
+  // resident workgroups), also in the branch-free peeled form that pays off for the split-bf16 kernels (-3...5 %: here
+  // a K step is 4096 MFMA cycles per wave, so there is little staging to hide); staggering co-resident workgroups +-0 %.  Timing-only ablations put the ceiling of
   // this structure (LDS reads + MFMA only) at 147 TF, global loads cost ~5 %, LDS stores + 2nd barrier ~5 %;
   // what recovers them is more resident workgroups per CU, hence the 64x64 tile for small / ragged problems.
   const float* As_w = As + wm * (BM / WM) * LDA;
