@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "multimodal-learning-with-alternating-unim
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_SPLIT_TFLOPS = 16 * 157.3 / 6  # conv_math=split: bf16 MFMA (16x the fp32 rate, ~2.5 PF dense), six products per fp32 product
 SPEC_HW, FRAMES, IMG_HW, N_CLASSES = (1024, 128), 3, (224, 224), 6
 
@@ -212,7 +213,28 @@ def main() -> None:
             tj = json.load(open(tpath))
             traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/r01_igemm_traffic.json: " + tj["method"]
         per_kind = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
-                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()}
+                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items() if k.startswith("conv")}
+        # HBM family: BatchNorm forward / backward against 8 TB/s; `achieved` = algorithmic bytes / time
+        # (12 B/elem forward, 20 B/elem backward), `moved` = what these kernels really read + write (the forward
+        # statistics come out of the conv epilogue, so it moves 8-12 B/elem).
+        hbm = {"ms": 0.0, "work": 0.0, "moved": 0.0}
+        for k in ("bn_fwd", "bn_bwd"):
+            for f in hbm:
+                hbm[f] += summ.get(k, {}).get(f, 0.0)
+            v = summ.get(k)
+            if v and v["ms"] > 0:
+                per_kind[k] = {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
+                               "algorithmic_GBps": round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1),
+                               "moved_GBps": round(v["moved"] / (v["ms"] * 1e-3) / 1e9, 1)}
+        hbm_roof = None
+        if hbm["ms"] > 0:
+            ach = hbm["work"] / (hbm["ms"] * 1e-3) / 1e9
+            hbm_roof = {"bound": "hbm", "kernels": "BatchNorm family (bn_finalize / bn_apply / bn_reduce / bn_bwd_apply)",
+                        "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBPS, 4),
+                        "moved_GBps": round(hbm["moved"] / (hbm["ms"] * 1e-3) / 1e9, 1),
+                        "algorithmic_GB_per_step": round(hbm["work"] / a.steps / 1e9, 2), "ms_per_step": round(hbm["ms"] / a.steps, 3)}
+        conv_flop = sum(v["work"] for k, v in summ.items() if k.startswith("conv")) / a.steps
+        t_min_ms = conv_flop / (peak * 1e12) * 1e3 + (hbm["work"] / a.steps) / (PEAK_HBM_GBPS * 1e9) * 1e3
         out = {
             "metric": "samples/sec per MLA alternating step, CREMA-D A+V bs=64",
             "value": round(B * world * a.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
@@ -232,6 +254,9 @@ def main() -> None:
                          "traffic_source": traffic_src},
             "overlap": {"side_stream": bool(overlapped), "ms_per_step_serialized": round(dt_serial / a.steps * 1e3, 3),
                         "conv_tflops_in_timed_region": round(sum(v["work"] for v in summ.values()) / dt / 1e12, 2)},
+            "roofline_hbm": hbm_roof,
+            "step_vs_t_min": {"t_min_ms": round(t_min_ms, 2), "frac": round(t_min_ms / (dt / a.steps * 1e3), 4),
+                              "definition": "T_min = conv FLOPs / MFMA peak + BN bytes / HBM peak (SURVEY 8d)"},
             "kernels": per_kind,
             "final_loss": round(loss, 5),
         }

@@ -31,19 +31,21 @@ class KernelTimer:
         e.record()
         return e
 
-    def end(self, kind: str, work: float, start) -> None:
+    def end(self, kind: str, work: float, start, moved: float = 0.0) -> None:
+        """work = algorithmic FLOPs / bytes of the call; moved = bytes the kernels really move (HBM family)."""
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        self.records.append((kind, work, start, e))
+        self.records.append((kind, work, start, e, moved))
 
     def summary(self) -> dict:
-        """kind -> {'launches', 'ms', 'work'} (call after torch.cuda.synchronize())."""
+        """kind -> {'launches', 'ms', 'work', 'moved'} (call after torch.cuda.synchronize())."""
         out: dict = {}
-        for kind, work, s, e in self.records:
-            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "work": 0.0})
+        for kind, work, s, e, moved in self.records:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "work": 0.0, "moved": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["work"] += work
+            d["moved"] += moved
         return out
 
 
@@ -250,14 +252,20 @@ def bn_stats_partial(x2d: torch.Tensor, M: int, C: int, partial: torch.Tensor, s
 def bn_finalize(partial: torch.Tensor, tiles: int, M: int, C: int, mean: torch.Tensor, invstd: torch.Tensor,
                 running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
                 eps: float = BN_EPS, momentum: float = BN_MOMENTUM, stream: Optional[int] = None) -> None:
+    t0 = TIMER.begin() if TIMER is not None else None
     check(_lib.load().mla_bn_finalize(_p(partial), tiles, M, C, eps, momentum, _p(mean), _p(invstd), _p(running_mean),
                                       _p(running_var), stream or cur_stream()), "mla_bn_finalize")
+    if t0 is not None:
+        TIMER.end("bn_fwd", 0.0, t0)      # statistics finalize: its time belongs to the BN forward, its bytes are negligible
 
 
 def bn_apply(x: torch.Tensor, mean, invstd, gamma, beta, out: torch.Tensor, M: int, C: int, relu: bool,
              residual: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+    t0 = TIMER.begin() if TIMER is not None else None
     check(_lib.load().mla_bn_apply(_p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(residual), _p(out), M, C,
                                    int(relu), stream or cur_stream()), "mla_bn_apply")
+    if t0 is not None:   # BN-fwd-train = 12 B/elem algorithmic; this path moves 8 (+4 with a residual)
+        TIMER.end("bn_fwd", 12.0 * M * C, t0, moved=(12.0 if residual is not None else 8.0) * M * C)
     return out
 
 
@@ -267,8 +275,11 @@ def bn_bwd_ws_elems(M: int, C: int) -> int:
 
 def bn_bwd(dout, x, mean, invstd, gamma, dx, dgamma, dbeta, ws, M: int, C: int, relu_out=None, g_out=None,
            stream: Optional[int] = None) -> None:
+    t0 = TIMER.begin() if TIMER is not None else None
     check(_lib.load().mla_bn_bwd(_p(dout), _p(relu_out), _p(x), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgamma),
                                  _p(dbeta), _p(g_out), _p(ws), M, C, stream or cur_stream()), "mla_bn_bwd")
+    if t0 is not None:   # BN-bwd = 20 B/elem (dy, x for the reductions; dy, x again; write dx)
+        TIMER.end("bn_bwd", 20.0 * M * C, t0, moved=20.0 * M * C)
 
 
 # ---- pooling ------------------------------------------------------------------------------------
