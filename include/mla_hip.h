@@ -76,7 +76,7 @@ int mla_conv2d_wgrad(const float* x, const float* dy, float* dw_hwio,
  * measurements; 6 is the default and the only set the parity tests bless. */
 size_t mla_conv2d_wsplit_bytes(int Cin, int Cout, int KH, int KW);
 int mla_conv2d_wsplit(const float* w_hwio, void* wsplit, int Cin, int Cout, int KH, int KW, int transposed, void* stream);
-/* Batched form (one launch for all convs of a flat parameter buffer).  desc: n <= 64 rows of 8 ints in DEVICE memory,
+/* Batched form (one launch for all convs of a flat parameter buffer).  desc: n <= 4096 rows of 8 ints in DEVICE memory,
  * {w_off (floats from params), out_off (16-bit elements from wsplit), taps, Cin, Cout, transposed, first_block, 0} with
  * first_block the running sum of taps*ceil(Cin/32)*ceil(Cout/32); total_blocks = that sum over all rows. */
 int mla_conv2d_wsplit_batch(const float* params, void* wsplit, const int* desc, int n, int total_blocks, void* stream);
@@ -159,6 +159,18 @@ int mla_linear_dgrad(const float* dy, const float* w_kn, float* dx, const float*
 size_t mla_linear_wgrad_ws_bytes(int M, int K, int N);
 int mla_linear_wgrad(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows, int x_off,
                      int K, int N, void* ws, size_t ws_bytes, void* stream);
+/* The same three on the split-bf16 arithmetic (see mla_conv2d_*_split): weights pre-split with
+ * mla_conv2d_wsplit(w_kn, out, Cin = K, Cout = N, 1, 1, transposed, stream), transposed = 1 for the forward image
+ * (wsplit_t), 0 for the input-gradient image (wsplit). */
+int mla_linear_fwd_split(const float* x, const void* wsplit_t, const float* bias, const float* residual, float* y,
+                         float* y_gelu, int groups, int rows, int x_group_rows, int x_off, int y_group_rows, int y_off,
+                         int K, int N, void* stream);
+int mla_linear_dgrad_split(const float* dy, const void* wsplit, float* dx, const float* residual, const float* gelu_src,
+                           int groups, int rows, int dy_group_rows, int dy_off, int dx_group_rows, int dx_off,
+                           int K, int N, void* stream);
+size_t mla_linear_wgrad_split_ws_bytes(int M, int K, int N);
+int mla_linear_wgrad_split(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows, int x_off,
+                           int K, int N, void* ws, size_t ws_bytes, void* stream);
 /* out[c] = sum_rows x[r][c]  (bias gradients).  ws: mla_colreduce_ws_elems(M, C) floats; C % 64 == 0. */
 size_t mla_colreduce_ws_elems(int M, int C);
 int mla_colsum_rows(const float* x, float* out, float* ws, int M, int C, void* stream);

@@ -553,25 +553,6 @@ extern "C" int mla_conv2d_wgrad(const float* x, const float* dy, float* dw, int 
 // `rows` consecutive tokens, taken at offset *_off inside groups of *_group_rows tokens, so the sub-range
 // "tokens 1..256 of each 257-token sequence" needs no copy.  w is [K][N] (= nn.Linear.weight transposed).
 // ---------------------------------------------------------------------------------------------
-static int linear_geom(const char* who, IGemmGeom& g, int groups, int rows, int in_group_rows, int in_off,
-                       int out_group_rows, int out_off, int K, int N) {
-  MLA_REQUIRE(groups > 0 && rows > 0 && K > 0 && N > 0, "%s: non-positive dims", who);
-  MLA_REQUIRE(K % 64 == 0 && N % 64 == 0 && K <= 8192 && N <= 8192, "%s: K=%d, N=%d must be multiples of 64", who, K, N);
-  MLA_REQUIRE(in_off >= 0 && in_off + rows <= in_group_rows && out_off >= 0 && out_off + rows <= out_group_rows && in_off < 128,
-              "%s: row window outside its group", who);
-  MLA_REQUIRE((long)groups * in_group_rows * K * 4 < 0xFFFFFFF0L && (long)groups * out_group_rows * N * 4 < 0xFFFFFFF0L,
-              "%s: tensors must be < 4 GiB", who);
-  g = IGemmGeom{};
-  g.N = groups; g.H = in_group_rows; g.W = 1; g.C = K; g.CO = N;
-  g.OH = rows; g.OW = 1; g.sy = g.sx = 1;
-  g.OHF = out_group_rows; g.OWF = 1; g.osy = g.osx = 1; g.ooy = out_off; g.oox = 0;
-  g.T = 1; g.M = groups * rows; g.K = K;
-  g.tap[0] = pack_tap(in_off, 0, 0);
-  g.x_bytes = (unsigned)((size_t)groups * in_group_rows * K * 4);
-  g.w_bytes = (unsigned)((size_t)K * N * 4);
-  return MLA_OK;
-}
-
 extern "C" int mla_linear_fwd(const float* x, const float* w_kn, const float* bias, const float* residual, float* y,
                               float* y_gelu, int groups, int rows, int x_group_rows, int x_off, int y_group_rows,
                               int y_off, int K, int N, void* stream) {

@@ -477,8 +477,11 @@ __global__ __launch_bounds__(256) void weight_split_batch_kernel(const float* __
                                                                   const int* __restrict__ desc, int n) {
   __shared__ float tile[32][33];
   const int b = blockIdx.x;
-  int j = 0;
-  while (j + 1 < n && desc[(j + 1) * 8 + 6] <= b) ++j;   // n <= 64: a short scalar scan
+  int j = 0, hi = n - 1;                                  // last row whose first_block <= b (scalar binary search)
+  while (j < hi) {
+    const int mid = (j + hi + 1) >> 1;
+    if (desc[mid * 8 + 6] <= b) j = mid; else hi = mid - 1;
+  }
   const int* d = desc + j * 8;
   const int T = d[2], CI = d[3], CO = d[4];
   const int tc = (CO + 31) / 32, tr = (CI + 31) / 32;
@@ -566,7 +569,7 @@ extern "C" int mla_conv2d_wsplit(const float* w, void* wsplit, int Cin, int Cout
 
 extern "C" int mla_conv2d_wsplit_batch(const float* params, void* wsplit, const int* desc, int n, int total_blocks, void* stream) {
   MLA_REQUIRE(params && wsplit && desc, "mla_conv2d_wsplit_batch: null pointer");
-  MLA_REQUIRE(n > 0 && n <= 64 && total_blocks > 0, "mla_conv2d_wsplit_batch: n=%d (1..64), total_blocks=%d", n, total_blocks);
+  MLA_REQUIRE(n > 0 && n <= 4096 && total_blocks > 0, "mla_conv2d_wsplit_batch: n=%d (1..4096), total_blocks=%d", n, total_blocks);
   weight_split_batch_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(params, (unsigned short*)wsplit, desc, n);
   MLA_CHECK_LAUNCH("weight_split_batch_kernel");
   return MLA_OK;
@@ -648,4 +651,57 @@ extern "C" int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw
   }
   MLA_CHECK_LAUNCH("wgrad_split_kernel");
   return mla_wgrad_reduce(part, dw, (size_t)g.T * Cin * Cout / 4, splits, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear layers of the transformer encoders on the split arithmetic (same row-window geometry as mla_linear_*).
+// wsplit_t / wsplit = mla_conv2d_wsplit(w_kn, ., Cin = K, Cout = N, 1, 1, transposed = 1 / 0, .).
+// ---------------------------------------------------------------------------------------------
+extern "C" int mla_linear_fwd_split(const float* x, const void* wsplit_t, const float* bias, const float* residual, float* y,
+                                    float* y_gelu, int groups, int rows, int x_group_rows, int x_off, int y_group_rows,
+                                    int y_off, int K, int N, void* stream) {
+  MLA_REQUIRE(x && wsplit_t && y, "mla_linear_fwd_split: null pointer");
+  IGemmGeom g;
+  if (int rc = linear_geom("mla_linear_fwd_split", g, groups, rows, x_group_rows, x_off, y_group_rows, y_off, K, N)) return rc;
+  return launch_split(x, wsplit_t, y, residual, nullptr, nullptr, g, pick_scfg(g.M, N, 1), (hipStream_t)stream, bias, y_gelu);
+}
+
+extern "C" int mla_linear_dgrad_split(const float* dy, const void* wsplit, float* dx, const float* residual,
+                                      const float* gelu_src, int groups, int rows, int dy_group_rows, int dy_off,
+                                      int dx_group_rows, int dx_off, int K, int N, void* stream) {
+  MLA_REQUIRE(dy && wsplit && dx, "mla_linear_dgrad_split: null pointer");
+  IGemmGeom g;   // GEMM: [M][N] x [N][K] -> [M][K]
+  if (int rc = linear_geom("mla_linear_dgrad_split", g, groups, rows, dy_group_rows, dy_off, dx_group_rows, dx_off, N, K)) return rc;
+  g.epi = 1;
+  return launch_split(dy, wsplit, dx, residual, gelu_src, nullptr, g, pick_scfg(g.M, K, 1), (hipStream_t)stream);
+}
+
+extern "C" size_t mla_linear_wgrad_split_ws_bytes(int M, int K, int N) {
+  int span, splits;
+  wgrad_split_plan(M, K, N, 1, &span, &splits);
+  return (size_t)splits * K * N * sizeof(float);
+}
+
+extern "C" int mla_linear_wgrad_split(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows,
+                                      int x_off, int K, int N, void* ws, size_t ws_bytes, void* stream) {
+  MLA_REQUIRE(x && dy && dw_kn && ws, "mla_linear_wgrad_split: null pointer");
+  IGemmGeom g;
+  if (int rc = linear_geom("mla_linear_wgrad_split", g, groups, rows, x_group_rows, x_off, rows, 0, K, N)) return rc;
+  g.y_bytes = (unsigned)((size_t)g.M * N * 4);
+  hipStream_t st = (hipStream_t)stream;
+  int span, splits;
+  wgrad_split_plan(g.M, K, N, 1, &span, &splits);
+  const size_t need = (size_t)splits * K * N * sizeof(float);
+  if (ws_bytes < need) {
+    mla_set_error("mla_linear_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
+    return MLA_ERR_WORKSPACE;
+  }
+  float* part = (float*)ws;
+  if (K % 128 == 0 && N % 128 == 0) {
+    wgrad_split_kernel<128, 128, 2, 2><<<dim3((K / 128) * (N / 128), splits), 256, 0, st>>>(x, dy, part, g, span);
+  } else {
+    wgrad_split_kernel<64, 64, 2, 2><<<dim3((K / 64) * (N / 64), splits), 256, 0, st>>>(x, dy, part, g, span);
+  }
+  MLA_CHECK_LAUNCH("wgrad_split_kernel");
+  return mla_wgrad_reduce(part, dw_kn, (size_t)K * N / 4, splits, st);
 }

@@ -13,6 +13,7 @@ encoder and vice versa) live outside the flat buffer: their gradient is None in 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -51,9 +52,13 @@ class M3AEEncoder:
                     ("transformer_mlp.fc1.bias", "4D"), ("transformer_mlp.fc2.weight", "4D,D"), ("transformer_mlp.fc2.bias", "D")]
 
     def __init__(self, kind: str, device="cuda", depth: int = 12, emb_dim: int = 768, num_heads: int = 12,
-                 text_vocab_size: int = 30522, patch_dim: int = 768, seed: Optional[int] = None):
+                 text_vocab_size: int = 30522, patch_dim: int = 768, seed: Optional[int] = None, conv_math: Optional[str] = None):
         if kind not in ("text", "image", "audio"):
             raise ValueError("kind must be 'text', 'image' or 'audio'")
+        self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", "f32")     # arithmetic of the Linear GEMMs (encoder.py)
+        if self.conv_math not in ("f32", "split"):
+            raise MLAHipError(f"conv_math must be 'f32' or 'split', got {self.conv_math!r}")
+        self.split = self.conv_math == "split"
         self.kind, self.device = kind, torch.device(device)
         if kind == "audio":
             patch_dim = 256                  # conv 16x16 over 1 channel (cav_mae.py:127)
@@ -98,7 +103,39 @@ class M3AEEncoder:
         self._pos: Dict[int, torch.Tensor] = {}
         self._ws: dict = {}
         self._key = None
+        # split-bf16 images of every Linear weight ([K][N] = a 1-tap conv weight): forward (transposed) and input-gradient
+        self.wsp: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.training, self._wsplit_dirty = True, True
+        if self.split:
+            lin = [k for k, (_o, shp) in self.layout.items() if len(shp) == 2 and k.endswith(".weight") and k != "text_embedding.weight"]
+            tot16 = sum(2 * 3 * math.prod(self.layout[k][1]) for k in lin)
+            self._wsplit_flat = torch.empty(tot16, device=self.device, dtype=torch.int16)
+            o16, rows, blocks = 0, [], 0
+            for k in lin:
+                off, (K, N) = self.layout[k]
+                n16 = 3 * K * N
+                self.wsp[k] = (self._wsplit_flat[o16:o16 + n16], self._wsplit_flat[o16 + n16:o16 + 2 * n16])
+                nb = ((K + 31) // 32) * ((N + 31) // 32)
+                for transposed, o in ((1, o16), (0, o16 + n16)):
+                    rows.append([off, o, 1, K, N, transposed, blocks, 0])
+                    blocks += nb
+                o16 += 2 * n16
+            self._wsplit_desc = torch.tensor(rows, dtype=torch.int32, device=self.device)
+            self._wsplit_blocks = blocks
         self.reset_parameters(seed)
+
+    def _w(self, name: str, which: int):
+        """split image of Linear `name` (0: forward, 1: input gradient) or None in f32 mode"""
+        e = self.wsp.get(name)
+        return None if e is None else e[which]
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        self._wsplit_dirty = True
+        return self
+
+    def eval(self):
+        return self.train(False)
 
     # ------------------------------------------------------------------------------------------
     def reset_parameters(self, seed: Optional[int] = None) -> None:
@@ -184,6 +221,7 @@ class M3AEEncoder:
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
+        self._wsplit_dirty = True
         for name in list(self.layout) + list(self.unused):
             key = prefix + self._ref_name(name)
             if key not in sd:
@@ -262,8 +300,8 @@ class M3AEEncoder:
         ws["dqkv"] = torch.empty((M, 3 * D), **f32)
         ws["dP"] = torch.empty((B, H, n, n), **f32)
         ws["wt_ws"] = torch.empty(4 * D * D, **f32)
-        wb = max(ops.linear_wgrad_ws_bytes(M, D, 3 * D), ops.linear_wgrad_ws_bytes(M, D, 4 * D), ops.linear_wgrad_ws_bytes(M, 4 * D, D),
-                 ops.linear_wgrad_ws_bytes(M, D, D), ops.linear_wgrad_ws_bytes(B * ws["L"], self.PD, D))
+        wb = max(ops.linear_wgrad_ws_bytes(m_, k_, n_, sp) for sp in ((False, True) if self.split else (False,))
+                 for (m_, k_, n_) in ((M, D, 3 * D), (M, D, 4 * D), (M, 4 * D, D), (M, D, D), (B * ws["L"], self.PD, D)))
         ws["wgrad_ws"] = torch.empty((wb + 3) // 4, **f32)
         ws["red_ws"] = torch.empty(ops.colreduce_ws_elems(M, 4 * D), **f32)
         ws["colsum"] = torch.empty(D, **f32)
@@ -275,6 +313,9 @@ class M3AEEncoder:
         st = ops.cur_stream()
         D, H = self.D, self.H
         hd = D // H
+        if self.split and (self.training or self._wsplit_dirty):
+            ops.conv2d_wsplit_batch(self.flat, self._wsplit_flat, self._wsplit_desc, self._wsplit_blocks, stream=st)
+            self._wsplit_dirty = False
         if self.kind == "text":
             ids = inp.reshape(inp.shape[0], -1).contiguous()                                 # token.squeeze(1)
             B, L = ids.shape
@@ -294,7 +335,7 @@ class M3AEEncoder:
             ws["pm"] = None
             ops.patchify(inp.contiguous().float(), ws["patches"], 16, transposed_hw=(F_, T_), stream=st)
             ops.linear_fwd(ws["patches"], self.p["patch_embed_a.proj.weight"], self.p["patch_embed_a.proj.bias"], ws["x0"], 1, B * L,
-                           self.PD, D, stream=st)
+                           self.PD, D, stream=st, wsplit=self._w("patch_embed_a.proj.weight", 0))
             ops.tokens_assemble(ws["x0"], None, None, self.p["pos_embed_a"], self.p["modality_a"], None, B, L, D, stream=st)
         else:
             B = inp.shape[0]
@@ -303,7 +344,7 @@ class M3AEEncoder:
             ws["pm"] = None
             ops.patchify(inp.contiguous(), ws["patches"], 16, stream=st)                     # basic_model.py:184-186
             ops.linear_fwd(ws["patches"], self.p["image_embedding.weight"], self.p["image_embedding.bias"], ws["x0"], B, L,
-                           self.PD, D, y_group_rows=L + 1, y_off=1, stream=st)               # m3ae.py:353
+                           self.PD, D, y_group_rows=L + 1, y_off=1, stream=st, wsplit=self._w("image_embedding.weight", 0))               # m3ae.py:353
             ops.tokens_assemble(ws["x0"], None, None, ws["pos"], self.p["encoder_image_type_embedding"], self.p["cls_token"],
                                 B, L, D, stream=st)
         n, M = ws["n"], ws["M"]
@@ -313,17 +354,17 @@ class M3AEEncoder:
             P_ = lambda nm: self.p[f"encoder.blocks.{i}.{nm}"]
             bk["x"] = x
             ops.layernorm_fwd(x, P_("layer_norm1.weight"), P_("layer_norm1.bias"), bk["h1"], bk["st"][0], bk["st"][1], M, D, stream=st)
-            ops.linear_fwd(bk["h1"], P_("attention.qkv_linear.weight"), P_("attention.qkv_linear.bias"), bk["qkv"], 1, M, D, 3 * D, stream=st)
+            ops.linear_fwd(bk["h1"], P_("attention.qkv_linear.weight"), P_("attention.qkv_linear.bias"), bk["qkv"], 1, M, D, 3 * D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.qkv_linear.weight", 0))
             qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
             ops.bgemm(bk["qkv"], bk["qkv"], bk["P"], B, H, n, n, hd, qs, (n * 3 * D, hd, 1, 3 * D), ss, scale, b_off=D, stream=st)   # m3ae.py:109
             ops.softmax_fwd(bk["P"], ws["pm"], B, H, n, stream=st)                                                                    # :111-118
             ops.bgemm(bk["P"], bk["qkv"], bk["o"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), os_, 1.0, b_off=2 * D, stream=st)   # :121-122
-            ops.linear_fwd(bk["o"], P_("attention.fc.weight"), P_("attention.fc.bias"), bk["xmid"], 1, M, D, D, residual=x, stream=st)  # :123,149
+            ops.linear_fwd(bk["o"], P_("attention.fc.weight"), P_("attention.fc.bias"), bk["xmid"], 1, M, D, D, residual=x, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.fc.weight", 0))  # :123,149
             ops.layernorm_fwd(bk["xmid"], P_("layer_norm2.weight"), P_("layer_norm2.bias"), bk["h2"], bk["st"][2], bk["st"][3], M, D, stream=st)
             ops.linear_fwd(bk["h2"], P_("transformer_mlp.fc1.weight"), P_("transformer_mlp.fc1.bias"), bk["u"], 1, M, D, 4 * D,
-                           y_gelu=bk["gl"], stream=st)                                                                               # :76-77
+                           y_gelu=bk["gl"], stream=st, wsplit=self._w(f"encoder.blocks.{i}.transformer_mlp.fc1.weight", 0))                                                                               # :76-77
             ops.linear_fwd(bk["gl"], P_("transformer_mlp.fc2.weight"), P_("transformer_mlp.fc2.bias"), bk["xout"], 1, M, 4 * D, D,
-                           residual=bk["xmid"], stream=st)                                                                            # :79,154
+                           residual=bk["xmid"], stream=st, wsplit=self._w(f"encoder.blocks.{i}.transformer_mlp.fc2.weight", 0))                                                                            # :79,154
             x = bk["xout"]
         ws["xlast"] = x
         ops.layernorm_fwd(x, self.p["encoder.layer_norm.weight"], self.p["encoder.layer_norm.bias"], ws["y"], ws["stf"][0], ws["stf"][1],
@@ -352,17 +393,17 @@ class M3AEEncoder:
             G_ = lambda nm: self.g[f"encoder.blocks.{i}.{nm}"]
             # ---- MLP: xout = xmid + fc2(gelu(fc1(LN2(xmid))))
             ops.colsum_rows(dx, G_("transformer_mlp.fc2.bias"), red, M, D, stream=st)
-            ops.linear_wgrad(bk["gl"], dx, G_("transformer_mlp.fc2.weight"), wgw, 1, M, 4 * D, D, stream=st)
-            ops.linear_dgrad(dx, P_("transformer_mlp.fc2.weight"), ws["du"], wtw, 1, M, 4 * D, D, gelu_src=bk["u"], stream=st)
+            ops.linear_wgrad(bk["gl"], dx, G_("transformer_mlp.fc2.weight"), wgw, 1, M, 4 * D, D, stream=st, split=self.split)
+            ops.linear_dgrad(dx, P_("transformer_mlp.fc2.weight"), ws["du"], wtw, 1, M, 4 * D, D, gelu_src=bk["u"], stream=st, wsplit=self._w(f"encoder.blocks.{i}.transformer_mlp.fc2.weight", 1))
             ops.colsum_rows(ws["du"], G_("transformer_mlp.fc1.bias"), red, M, 4 * D, stream=st)
-            ops.linear_wgrad(bk["h2"], ws["du"], G_("transformer_mlp.fc1.weight"), wgw, 1, M, D, 4 * D, stream=st)
-            ops.linear_dgrad(ws["du"], P_("transformer_mlp.fc1.weight"), dB_, wtw, 1, M, D, 4 * D, stream=st)   # d h2
+            ops.linear_wgrad(bk["h2"], ws["du"], G_("transformer_mlp.fc1.weight"), wgw, 1, M, D, 4 * D, stream=st, split=self.split)
+            ops.linear_dgrad(ws["du"], P_("transformer_mlp.fc1.weight"), dB_, wtw, 1, M, D, 4 * D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.transformer_mlp.fc1.weight", 1))   # d h2
             ops.layernorm_bwd(dB_, bk["xmid"], P_("layer_norm2.weight"), bk["st"][2], bk["st"][3], dB_, G_("layer_norm2.weight"),
                               G_("layer_norm2.bias"), red, M, D, add=dx, stream=st)                             # d xmid -> dB_
             # ---- attention: xmid = x + fc(PV)
             ops.colsum_rows(dB_, G_("attention.fc.bias"), red, M, D, stream=st)
-            ops.linear_wgrad(bk["o"], dB_, G_("attention.fc.weight"), wgw, 1, M, D, D, stream=st)
-            ops.linear_dgrad(dB_, P_("attention.fc.weight"), dC, wtw, 1, M, D, D, stream=st)                    # d o (B,n,D)
+            ops.linear_wgrad(bk["o"], dB_, G_("attention.fc.weight"), wgw, 1, M, D, D, stream=st, split=self.split)
+            ops.linear_dgrad(dB_, P_("attention.fc.weight"), dC, wtw, 1, M, D, D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.fc.weight", 1))                    # d o (B,n,D)
             qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
             ops.bgemm(dC, bk["qkv"], ws["dP"], B, H, n, n, hd, os_, (n * 3 * D, hd, 1, 3 * D), ss, 1.0, b_off=2 * D, stream=st)          # dP = dO V^T
             ops.bgemm(bk["P"], dC, ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * D, hd, D, 1), qs, 1.0, c_off=2 * D, stream=st)   # dV = P^T dO
@@ -371,8 +412,8 @@ class M3AEEncoder:
             ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * 3 * D, hd, 3 * D, 1), qs, scale,
                       c_off=D, stream=st)                                                                                                # dK = s dS^T Q
             ops.colsum_rows(ws["dqkv"], G_("attention.qkv_linear.bias"), red, M, 3 * D, stream=st)
-            ops.linear_wgrad(bk["h1"], ws["dqkv"], G_("attention.qkv_linear.weight"), wgw, 1, M, D, 3 * D, stream=st)
-            ops.linear_dgrad(ws["dqkv"], P_("attention.qkv_linear.weight"), dC, wtw, 1, M, D, 3 * D, stream=st)  # d h1
+            ops.linear_wgrad(bk["h1"], ws["dqkv"], G_("attention.qkv_linear.weight"), wgw, 1, M, D, 3 * D, stream=st, split=self.split)
+            ops.linear_dgrad(ws["dqkv"], P_("attention.qkv_linear.weight"), dC, wtw, 1, M, D, 3 * D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.qkv_linear.weight", 1))  # d h1
             ops.layernorm_bwd(dC, bk["x"], P_("layer_norm1.weight"), bk["st"][0], bk["st"][1], dC, G_("layer_norm1.weight"),
                               G_("layer_norm1.bias"), red, M, D, add=dB_, stream=st)                            # d x -> dC
             dx, dC = dC, dx                                                                                     # rotate buffers
@@ -387,7 +428,7 @@ class M3AEEncoder:
             if "red_pos" not in ws:
                 ws["red_pos"] = torch.empty(ops.colreduce_ws_elems(B, L * D), device=self.device, dtype=torch.float32)
             ops.colsum_rows(dx, self.g["pos_embed_a"], ws["red_pos"], B, L * D, stream=st)
-            ops.linear_wgrad(ws["patches"], dx, self.g["patch_embed_a.proj.weight"], wgw, 1, B * L, self.PD, D, stream=st)
+            ops.linear_wgrad(ws["patches"], dx, self.g["patch_embed_a.proj.weight"], wgw, 1, B * L, self.PD, D, stream=st, split=self.split)
         elif self.kind == "text":
             self.g["text_embedding.weight"].zero_()
             ops.tokens_assemble_bwd(dx, ws["colsum"], ws["ids"], self.g["cls_token"], self.g["encoder_text_type_embedding"],
@@ -397,13 +438,14 @@ class M3AEEncoder:
                                     B, L, D, stream=st)
             dimg = dx.view(B, n, D)[:, 1:, :].contiguous().view(B * L, D)       # memory plumbing: drop the cls rows
             ops.colsum_rows(dimg, self.g["image_embedding.bias"], red, B * L, D, stream=st)
-            ops.linear_wgrad(ws["patches"], dimg, self.g["image_embedding.weight"], wgw, 1, B * L, self.PD, D, stream=st)
+            ops.linear_wgrad(ws["patches"], dimg, self.g["image_embedding.weight"], wgw, 1, B * L, self.PD, D, stream=st, split=self.split)
 
 
 class M3AEClassifier:
     """models/basic_model.py:127-200 under --gs_flag: mae_a (text) + mae_v (image) + ConcatFusion(768 -> C)."""
 
-    def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None):
+    def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None,
+                 conv_math: Optional[str] = None):
         from .model import ConcatFusion, N_CLASSES
         fusion = getattr(args, "fusion_method", "concat")
         dataset = getattr(args, "dataset", "Food101")
@@ -416,8 +458,8 @@ class M3AEClassifier:
         self.args, self.device = args, torch.device(device)
         s = (lambda k: None if seed is None else seed + k)
         self.fusion_module = ConcatFusion(768, N_CLASSES[dataset], device, s(2))   # basic_model.py:149
-        self.mae_a = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(0))    # :166
-        self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1))   # :167
+        self.mae_a = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(0), conv_math=conv_math)    # :166
+        self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1), conv_math=conv_math)   # :167
         self.module = self
 
     def mla_encoders(self):
@@ -425,6 +467,8 @@ class M3AEClassifier:
 
     def train(self, mode: bool = True):      # LayerNorm / no dropout (att_drop = drop = drop_path = 0): mode-free
         self.training = bool(mode)
+        for _t, _g, enc in self.mla_encoders():
+            enc.train(mode)
         return self
 
     def eval(self):
@@ -468,7 +512,8 @@ class Modal3Classifier:
     """models/basic_model.py:202-275 under --gs_flag: CAV-MAE audio (mae_a) + M3AE image (mae_v) + M3AE text (mae_t),
     shared head Linear(768 -> 4); MLA alternates a -> v -> t (main.py:432-466)."""
 
-    def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None):
+    def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None,
+                 conv_math: Optional[str] = None):
         from .model import N_CLASSES
         fusion = getattr(args, "fusion_method", "concat")
         dataset = getattr(args, "dataset", "IEMOCAP")
@@ -481,9 +526,9 @@ class Modal3Classifier:
         self.args, self.device = args, torch.device(device)
         s = (lambda k: None if seed is None else seed + k)
         self.fusion_module = ConcatFusion3(768, N_CLASSES[dataset], device, s(3))  # basic_model.py:218
-        self.mae_a = M3AEEncoder("audio", device, depth=depth, seed=s(0))                                     # :231 CAVMAEFT
-        self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1))   # :232
-        self.mae_t = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(2))    # :233
+        self.mae_a = M3AEEncoder("audio", device, depth=depth, seed=s(0), conv_math=conv_math)                                     # :231 CAVMAEFT
+        self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1), conv_math=conv_math)   # :232
+        self.mae_t = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(2), conv_math=conv_math)    # :233
         self.module = self
 
     def mla_encoders(self):
@@ -491,6 +536,8 @@ class Modal3Classifier:
 
     def train(self, mode: bool = True):
         self.training = bool(mode)
+        for _t, _g, enc in self.mla_encoders():
+            enc.train(mode)
         return self
 
     def eval(self):

@@ -341,26 +341,44 @@ LN_EPS = 1e-5     # nn.LayerNorm default (models/m3ae.py:138)
 
 
 def linear_fwd(x, w_kn, bias, y, groups: int, rows: int, K: int, N: int, x_group_rows: Optional[int] = None, x_off: int = 0,
-               y_group_rows: Optional[int] = None, y_off: int = 0, residual=None, y_gelu=None, stream: Optional[int] = None):
-    """y[g][y_off+r] = x[g][x_off+r] @ w_kn (+bias) (+residual); y_gelu (optional) also receives gelu(y)."""
+               y_group_rows: Optional[int] = None, y_off: int = 0, residual=None, y_gelu=None, stream: Optional[int] = None,
+               wsplit=None):
+    """y[g][y_off+r] = x[g][x_off+r] @ w_kn (+bias) (+residual); y_gelu (optional) also receives gelu(y).
+    wsplit: conv2d_wsplit(w_kn.view(1, 1, K, N), True) selects the split-bf16 arithmetic."""
+    if wsplit is not None:
+        check(_lib.load().mla_linear_fwd_split(_p(x), _p(wsplit, torch.int16), _p(bias), _p(residual), _p(y), _p(y_gelu), groups,
+                                               rows, x_group_rows or rows, x_off, y_group_rows or rows, y_off, K, N,
+                                               stream or cur_stream()), "mla_linear_fwd_split")
+        return
     check(_lib.load().mla_linear_fwd(_p(x), _p(w_kn), _p(bias), _p(residual), _p(y), _p(y_gelu), groups, rows,
                                      x_group_rows or rows, x_off, y_group_rows or rows, y_off, K, N,
                                      stream or cur_stream()), "mla_linear_fwd")
 
 
 def linear_dgrad(dy, w_kn, dx, wt_ws, groups: int, rows: int, K: int, N: int, residual=None, gelu_src=None,
-                 stream: Optional[int] = None):
-    """dx = dy @ w_kn^T (+residual) (* gelu'(gelu_src)); dense rows."""
+                 stream: Optional[int] = None, wsplit=None):
+    """dx = dy @ w_kn^T (+residual) (* gelu'(gelu_src)); dense rows.  wsplit: conv2d_wsplit(w_kn.view(1, 1, K, N), False)."""
+    if wsplit is not None:
+        check(_lib.load().mla_linear_dgrad_split(_p(dy), _p(wsplit, torch.int16), _p(dx), _p(residual), _p(gelu_src), groups,
+                                                 rows, rows, 0, rows, 0, K, N, stream or cur_stream()), "mla_linear_dgrad_split")
+        return
     check(_lib.load().mla_linear_dgrad(_p(dy), _p(w_kn), _p(dx), _p(residual), _p(gelu_src), _p(wt_ws), groups, rows,
                                        rows, 0, rows, 0, K, N, stream or cur_stream()), "mla_linear_dgrad")
 
 
-def linear_wgrad_ws_bytes(M: int, K: int, N: int) -> int:
+def linear_wgrad_ws_bytes(M: int, K: int, N: int, split: bool = False) -> int:
+    if split:
+        return int(_lib.load().mla_linear_wgrad_split_ws_bytes(M, K, N))
     return int(_lib.load().mla_linear_wgrad_ws_bytes(M, K, N))
 
 
 def linear_wgrad(x, dy, dw_kn, ws, groups: int, rows: int, K: int, N: int, x_group_rows: Optional[int] = None, x_off: int = 0,
-                 stream: Optional[int] = None):
+                 stream: Optional[int] = None, split: bool = False):
+    if split:
+        check(_lib.load().mla_linear_wgrad_split(_p(x), _p(dy), _p(dw_kn), groups, rows, x_group_rows or rows, x_off, K, N,
+                                                 _p(ws), ws.numel() * ws.element_size(), stream or cur_stream()),
+              "mla_linear_wgrad_split")
+        return
     check(_lib.load().mla_linear_wgrad(_p(x), _p(dy), _p(dw_kn), groups, rows, x_group_rows or rows, x_off, K, N, _p(ws),
                                        ws.numel() * ws.element_size(), stream or cur_stream()), "mla_linear_wgrad")
 

@@ -8,7 +8,7 @@ from mla_hip import M3AEClassifier, MLATrainer, ops
 
 B = int(os.environ.get("B", "64")); steps = int(os.environ.get("STEPS", "5")); depth = int(os.environ.get("DEPTH", "12"))
 class Args: fusion_method, dataset, gs_flag, modulation = "concat", "Food101", True, "Normal"
-model = M3AEClassifier(Args(), depth=depth, seed=1)
+model = M3AEClassifier(Args(), depth=depth, seed=1, conv_math=os.environ.get("MATH", "f32"))
 tr = MLATrainer(model)
 g = torch.Generator(device="cuda").manual_seed(0)
 token = torch.randint(0, 30522, (B, 1, 256), device="cuda", generator=g)
@@ -25,4 +25,4 @@ for s in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 flops = 2 * 3 * 2 * B * 257 * depth * (12 * 768 * 768 + 2 * 257 * 768)     # 12 d^2 + 2 N d MAC per token per layer
-print(f"M3AE MLA step: B={B} depth={depth}: {dt*1e3:.1f} ms/step, {B/dt:.1f} samples/s, ~{flops/dt/1e12:.1f} TFLOP/s (algorithmic), loss {tr.losses['loss'].item():.4f}")
+print(f"M3AE MLA step ({os.environ.get('MATH', 'f32')}): B={B} depth={depth}: {dt*1e3:.1f} ms/step, {B/dt:.1f} samples/s, ~{flops/dt/1e12:.1f} TFLOP/s (algorithmic), loss {tr.losses['loss'].item():.4f}")

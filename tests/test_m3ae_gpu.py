@@ -181,14 +181,15 @@ class _Args:
     fusion_method, dataset, gs_flag, modulation = "concat", "Food101", True, "Normal"
 
 
-def test_m3ae_step_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("conv_math", ["f32", "split"])
+def test_m3ae_step_vs_reference_golden(golden_dir, conv_math):
     from mla_hip import M3AEClassifier, MLATrainer
     import mla_hip.model as mm
     fx = np.load(os.path.join(golden_dir, "m3ae_small.npz"))
     B, depth, vocab, C, steps, seed = [int(v) for v in fx["meta"]]
     mm.N_CLASSES["Food101"] = C                                   # the fixture uses a small class count (fixture size)
     try:
-        model = M3AEClassifier(_Args(), depth=depth, text_vocab_size=vocab, seed=0)
+        model = M3AEClassifier(_Args(), depth=depth, text_vocab_size=vocab, seed=0, conv_math=conv_math)
     finally:
         mm.N_CLASSES["Food101"] = 101
     pa, pv = O.make_m3ae_params(seed, depth=depth, vocab=vocab), O.make_m3ae_params(seed + 1, depth=depth, vocab=vocab)
@@ -250,14 +251,15 @@ def test_m3ae_step_vs_reference_golden(golden_dir):
     assert tr.gs_plugin.exp_count == 2 * steps
 
 
+@pytest.mark.parametrize("conv_math", ["f32", "split"])
 @pytest.mark.parametrize("depth,B", [(2, 2), (12, 2)])
-def test_m3ae_encoder_grads_vs_oracle(depth, B):
+def test_m3ae_encoder_grads_vs_oracle(depth, B, conv_math):
     """Every parameter gradient of both modality encoders vs the autograd oracle (full depth 12 included)."""
     from mla_hip import M3AEEncoder
     vocab, seed = 300, 77
     for kind in ("text", "image"):
         p = O.make_m3ae_params(seed, depth=depth, vocab=vocab)
-        enc = M3AEEncoder(kind, depth=depth, text_vocab_size=vocab, seed=0)
+        enc = M3AEEncoder(kind, depth=depth, text_vocab_size=vocab, seed=0, conv_math=conv_math)
         enc.load_state_dict(p)
         leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
         dfeat = O.portable_normal(seed, (B, 768), stream=9)
