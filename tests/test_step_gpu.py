@@ -154,6 +154,29 @@ def test_step_vs_oracle_all_grads(B, spec_hw, T, img_hw, conv_math):
         sync_oracle_state_from_hip(st, model, tr)     # next step starts from identical state (momentum, Pl included)
 
 
+def test_baseline_config0_shapes_bs8():
+    """BASELINE.json configs[0] (the reference's CPU-runnable case): CREMA-D shapes -- spec 1x1024x128, 3 frames of
+    3x224x224 -- at batch 8, one MLA step from identical state: features, logits, losses, raw and projected head
+    gradient against the CPU oracle, both conv arithmetics (the oracle step is computed once)."""
+    seed, B = 5, 8
+    spec, image, label = inputs(seed, 0, B, (1024, 128), 3, (224, 224))
+    ref = None
+    for conv_math in ("f32", "split"):
+        model, tr, st = build(seed, "as_intended", False, conv_math)
+        if ref is None:
+            ref = O.mla_step(st, spec, image, label, 0, 100)
+        losses = tr.train_step(spec.cuda(), image.cuda(), label.cuda(), 0, 100)
+        torch.cuda.synchronize()
+        for k in ("a", "v", "out_a", "out_v"):
+            assert_close(tr.last[k], ref[k], atol=TOL, name=f"{conv_math} {k}")
+        for k in ("loss", "loss_a", "loss_v"):
+            assert_close(losses[k].reshape(()), ref[k], atol=TOL, name=f"{conv_math} {k}")
+        assert_close(tr.last["head_grad_a_raw"], ref["head_grad_a_raw"], atol=TOL, name=f"{conv_math} raw head grad a")
+        assert_close(model.fusion_module.fc_out.weight_grad, ref["head_grad_v"], atol=TOL, name=f"{conv_math} projected head grad")
+        del model, tr
+        torch.cuda.empty_cache()
+
+
 def test_adjoint_identities_full_size():
     """Size-independent property at the CREMA-D layer shapes (B=64): <dY, conv(X,W)> = <dgrad(dY), X> =
     <wgrad(X,dY), W>.  Exercises the three conv kernels at BASELINE.json's full sizes without a CPU oracle."""
