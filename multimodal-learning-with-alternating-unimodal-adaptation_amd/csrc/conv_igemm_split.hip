@@ -221,7 +221,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
   __syncthreads();
   // Steady state is branch-free so the scheduler can interleave the staging work with the MFMAs; the last two
   // stages (nothing left to load / to stage) are peeled.  Measured alternatives (l2 shape, 128x128 tile, 177 TF):
-  // a second register set with the loads of tile it+2 pinned at the top of step it: 3-7 % slower; a ring of three
+  // a second register set with the loads of tile it+2 pinned at the top of step it: 3-7 % slower, unpinned with a
+  // two-stage load distance: +2 % on the K >= 1152 layers, -4 % on the stride-2 parity classes; a ring of three
   // LDS buffers with the next step's first-half fragments fetched before the barrier: +-0; plane-wise fragment reads
   // issued one MFMA group ahead of their use, with and without sched_group_barrier pinning: +-1 %.  Timing-only ablations:
   // MFMAs alone reach the 6-product ceiling (333 TF at the sustained bf16 rate) once the tail of the last round is
