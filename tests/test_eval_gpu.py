@@ -18,9 +18,9 @@ class _Args:
     fusion_method, dataset, gs_flag, modulation = "concat", "CREMAD", True, "Normal"
 
 
-def _model(seed):
+def _model(seed, conv_math="f32"):
     from mla_hip import AVClassifier
-    model = AVClassifier(_Args(), seed=0)
+    model = AVClassifier(_Args(), seed=0, conv_math=conv_math)
     pa, pv = O.make_resnet18_params("audio", seed), O.make_resnet18_params("visual", seed + 1)
     hd = O.make_head_params(512, 6, seed + 2)
     for params, off in ((pa, 0), (pv, 500)):
@@ -35,12 +35,13 @@ def _model(seed):
     return model
 
 
+@pytest.mark.parametrize("conv_math", ["f32", "split"])
 @pytest.mark.parametrize("dynamic", [True, False])
-def test_valid_vs_reference_golden(dynamic, golden_dir):
+def test_valid_vs_reference_golden(dynamic, conv_math, golden_dir):
     from mla_hip import Evaluator
     fx = np.load(os.path.join(golden_dir, "eval_small.npz"))
     B, sh, sw, T, ih, iw, seed = [int(v) for v in fx["meta"]]
-    model = _model(seed)
+    model = _model(seed, conv_math)
     ev = Evaluator(model, dynamic=dynamic, av_alpha=0.5)
     spec = O.portable_normal(seed + 9, (B, sh, sw), stream=1, mean=-5.081, std=4.4849)
     image = O.portable_normal(seed + 9, (B, 3, T, ih, iw), stream=2)
