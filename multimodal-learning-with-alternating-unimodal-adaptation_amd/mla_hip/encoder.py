@@ -129,7 +129,17 @@ class ResNet18Encoder:
         # Optional second HIP stream for the weight-gradient GEMMs: they are off the dgrad -> BN-backward critical
         # chain, so (with one dy buffer per conv: 288 GB of HBM) they run beside it and fill its kernel tails.
         self.wgrad_stream: Optional[torch.cuda.Stream] = None
+        # Stream that carries this encoder's training chain (set by MLATrainer): anything that touches the encoder from
+        # another stream first waits for it (stream-ordered semantics for forward / state_dict / eval without a device sync).
+        self.tail_stream: Optional[torch.cuda.Stream] = None
         self.reset_parameters(seed)
+
+    def _await_tail(self) -> None:
+        ts = self.tail_stream
+        if ts is not None:
+            cur = torch.cuda.current_stream()
+            if cur != ts:
+                cur.wait_stream(ts)
 
     # ------------------------------------------------------------------------------------------
     # parameters / state_dict (reference keys and OIHW layout at the boundary)
@@ -150,6 +160,7 @@ class ResNet18Encoder:
             self.p[bn + ".bias"].zero_()
 
     def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
+        self._await_tail()
         sd = {}
         for name, *_ in self.specs:
             sd[prefix + name + ".weight"] = self.p[name + ".weight"].permute(3, 2, 0, 1).contiguous()
@@ -163,6 +174,7 @@ class ResNet18Encoder:
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
+        self._await_tail()
         for name, *_ in self.specs:
             keys = [name + ".weight"]
             bn = bn_name_for_conv(name)
@@ -188,6 +200,7 @@ class ResNet18Encoder:
 
     def grads_as_reference(self) -> Dict[str, torch.Tensor]:
         """Gradients keyed/laid out like the reference's named_parameters() (OIHW)."""
+        self._await_tail()
         out = {}
         for k in self.layout:
             t = self.g[k]
@@ -280,6 +293,7 @@ class ResNet18Encoder:
 
     def train(self, mode: bool = True):
         """nn.Module.train/eval semantics for the BatchNorm layers: eval uses the running statistics."""
+        self._await_tail()
         self.training = bool(mode)
         self._wsplit_dirty = True
         if not self.training:
@@ -318,6 +332,7 @@ class ResNet18Encoder:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,1,H,W) audio or (B,3,T,H,W) visual, fp32, reference layout.  Returns the NHWC feature
         map (N,h,w,512) of layer4 (backbone.py:142-160); activations are kept for backward()."""
+        self._await_tail()
         st = ops.cur_stream()
         if self.modality == "visual":
             if x.dim() != 5:

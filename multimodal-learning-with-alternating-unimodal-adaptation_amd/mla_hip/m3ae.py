@@ -105,6 +105,7 @@ class M3AEEncoder:
         self._key = None
         # split-bf16 images of every Linear weight ([K][N] = a 1-tap conv weight): forward (transposed) and input-gradient
         self.wsp: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.tail_stream: Optional[torch.cuda.Stream] = None     # see ResNet18Encoder.tail_stream
         self.training, self._wsplit_dirty = True, True
         if self.split:
             lin = [k for k, (_o, shp) in self.layout.items() if len(shp) == 2 and k.endswith(".weight") and k != "text_embedding.weight"]
@@ -123,6 +124,13 @@ class M3AEEncoder:
             self._wsplit_desc = torch.tensor(rows, dtype=torch.int32, device=self.device)
             self._wsplit_blocks = blocks
         self.reset_parameters(seed)
+
+    def _await_tail(self) -> None:
+        ts = self.tail_stream
+        if ts is not None:
+            cur = torch.cuda.current_stream()
+            if cur != ts:
+                cur.wait_stream(ts)
 
     def _w(self, name: str, which: int):
         """split image of Linear `name` (0: forward, 1: input gradient) or None in f32 mode"""
@@ -189,6 +197,7 @@ class M3AEEncoder:
 
     def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
         """Reference keys and layouts (nn.Linear.weight is (out, in); type embeddings / cls are (1,1,D))."""
+        self._await_tail()
         sd = {}
         for name in self.layout:
             t = self.p[name]
@@ -221,6 +230,7 @@ class M3AEEncoder:
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
+        self._await_tail()
         self._wsplit_dirty = True
         for name in list(self.layout) + list(self.unused):
             key = prefix + self._ref_name(name)
@@ -310,6 +320,7 @@ class M3AEEncoder:
     def forward(self, inp: torch.Tensor, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """text: inp = token ids (B,1,L) or (B,L) int64, padding_mask (B,1,L)/(B,L) float (1 = padded);
         image: inp = (B,3,256,256) fp32.  Returns the (B, D) token-mean feature (basic_model.py:182-200)."""
+        self._await_tail()
         st = ops.cur_stream()
         D, H = self.D, self.H
         hd = D // H

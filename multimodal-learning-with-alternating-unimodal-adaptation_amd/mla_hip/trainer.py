@@ -45,19 +45,36 @@ class MLATrainer:
         self._msg = torch.empty(self.head.numel + self.head.in_features + 1, device=dev, dtype=torch.float32)
         self.losses = {k: torch.zeros(1, device=dev, dtype=torch.float32) for k in ["loss"] + ["loss_" + t for t, _g, _e in self.encoders]}
         self.last = {}
-        # Second HIP stream: the forwards of the later modalities do not depend on the head or on earlier encoders
-        # (Q7), so they run beside the first modality's forward/backward and fill its kernel tails.
-        self.overlap_forward = dev.type == "cuda" and hasattr(model, "forward_split")
-        self._side = torch.cuda.Stream(device=dev) if self.overlap_forward else None       # later forwards + weight gradients
-        self._bstreams = [torch.cuda.Stream(device=dev) for _ in self.encoders] if self.overlap_forward else []   # backward chains
-        self.set_overlap(self.overlap_forward)
+        # One HIP stream per encoder carries that encoder's whole chain -- forward, backward, gradient all-reduce, SGD --
+        # and a second one its weight-gradient GEMMs; the stream train_step is called on carries only the head path
+        # (head forward/backward, packed head exchange, GSPlugin, head SGD) and hands features / feature gradients
+        # over with events.  No encoder forward depends on the head or on another encoder (Q7), the next modality only
+        # needs the updated head, and the next STEP's first forward only needs that encoder's own SGD, so the encoder
+        # chains run beside each other and across step boundaries (the last modality's backward overlaps the next
+        # step's first forward) and fill each other's kernel tails.
+        self._can_overlap = dev.type == "cuda" and hasattr(model, "forward_split")
+        self._estreams = [torch.cuda.Stream(device=dev) for _ in self.encoders] if self._can_overlap else []
+        self._wstreams = [torch.cuda.Stream(device=dev) for _ in self.encoders] if self._can_overlap else []
+        self.overlap_forward = False
+        self.set_overlap(self._can_overlap)
+
+    def join(self) -> None:
+        """Make the current stream wait for every encoder chain (parameters, momentum, gradients, BN buffers final).
+        Encoders do this themselves when they are used from another stream (forward, state_dict, ...); call it before
+        touching optimizer state or raw buffers on the current stream without a device synchronize."""
+        if self._estreams and torch.cuda.is_available():
+            cur = torch.cuda.current_stream()
+            for es in self._estreams:
+                cur.wait_stream(es)
 
     def set_overlap(self, on: bool) -> None:
-        """Side-stream overlap (later forwards beside the first phase; weight gradients beside the dgrad chain)."""
-        self.overlap_forward = bool(on) and self._side is not None
-        for _t, _g, enc in self.encoders:
+        """Per-encoder stream pipeline on / off (off: every kernel of the step on the current stream, in program order)."""
+        self.join()
+        self.overlap_forward = bool(on) and self._can_overlap
+        for k, (_t, _g, enc) in enumerate(self.encoders):
             if hasattr(enc, "wgrad_stream"):
-                enc.wgrad_stream = self._side if self.overlap_forward else None
+                enc.wgrad_stream = self._wstreams[k] if self.overlap_forward else None
+            enc.tail_stream = self._estreams[k] if self.overlap_forward else None
 
     keep_debug = False
 
@@ -65,8 +82,9 @@ class MLATrainer:
                batch_step: int, len_dataloader: int, bstream):
         """One modality phase (main.py:432-442).  Critical path on the current stream: head forward/backward ->
         (data parallel: packed head exchange) -> GSPlugin -> head SGD.  The encoder backward (and its gradient
-        all-reduce) is NOT on that path -- the next modality only needs the updated head -- so when `bstream` is given
-        it is enqueued there and runs beside the following phases.  Returns the all-reduce work handles."""
+        all-reduce) is NOT on that path -- the next modality only needs the updated head -- so when `bstream` (the
+        encoder's own stream) is given it is enqueued there and runs beside the following phases and the next step's
+        forwards.  Returns the all-reduce work handles."""
         logits, loss, dX = self.head.forward_backward(feat, label, inv_batch, slot=name)               # :432-435
         self.last["out_" + name] = logits
         self.losses["loss_" + name].copy_(loss)
@@ -120,27 +138,25 @@ class MLATrainer:
         B = label.shape[0]
         inv_batch = 1.0 / (B * self.comm.world)
         opt.zero_grad()                                                                       # main.py:164
-        main = torch.cuda.current_stream() if self.overlap_forward else None
-        side_done = None
+        fwd_done = []
         if self.overlap_forward:
+            main = torch.cuda.current_stream()
             fwds = m.forward_split(*inputs)                                                   # main.py:424-431 (joint forward, Q7)
-            self._side.wait_stream(main)                                                      # inputs / parameters are ready
-            with torch.cuda.stream(self._side):
-                later = [f() for f in fwds[1:]]
-                side_done = torch.cuda.Event()
-                side_done.record()
-            feats = [fwds[0]()] + later
+            feats = []
+            for es, f in zip(self._estreams, fwds):
+                es.wait_stream(main)       # inputs are ready; the previous step's head phases have read this encoder's features
+                with torch.cuda.stream(es):
+                    feats.append(f())      # stream order on `es`: after this encoder's SGD of the previous step
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    fwd_done.append(ev)
         else:
             feats = m.forward(*inputs)
-        n_enc = len(self.encoders)
-        bstreams = []
         for k, ((tag, grp, enc), feat) in enumerate(zip(self.encoders, feats)):
-            if k == 1 and side_done is not None:
-                torch.cuda.current_stream().wait_event(side_done)                             # later forwards have landed
+            bs = self._estreams[k] if self.overlap_forward else None
+            if bs is not None:
+                torch.cuda.current_stream().wait_event(fwd_done[k])                           # this encoder's features have landed
             self.last[tag] = feat
-            # every encoder but the last runs its backward / all-reduce / SGD on its own stream, beside the later phases
-            bs = self._bstreams[k] if (self.overlap_forward and k < n_enc - 1) else None
-            bstreams.append(bs)
             works = self._phase(tag, enc, feat, label, inv_batch, batch_step, len_dataloader, bs)
             opt.mark_ready(grp)
             with self._on(bs):
@@ -150,12 +166,8 @@ class MLATrainer:
                 for j in range(k):
                     g2 = self.encoders[j][1]
                     opt.grad_state[g2] = "zero"
-                    with self._on(bstreams[j]):
+                    with self._on(self._estreams[j] if self.overlap_forward else None):
                         opt.step_group(g2)
-        if main is not None:
-            for bs in bstreams:
-                if bs is not None:
-                    main.wait_stream(bs)                                                      # all parameters updated before the next step
         opt.drop_grads()                                                                      # main.py:468-470
         t0, t1 = self.encoders[0][0], self.encoders[1][0]
         torch.add(self.losses["loss_" + t0] * self.av_alpha, self.losses["loss_" + t1], alpha=1 - self.av_alpha,

@@ -249,8 +249,9 @@ def test_rccl_path_single_rank_matches_local():
 
 
 def test_stream_overlap_is_bitwise_equivalent():
-    """Side-stream overlap (later forwards, weight gradients, non-final encoder backward + SGD on their own streams) only
-    reorders independent kernels: parameters, momentum, Pl and losses after 3 steps equal the serialized trainer's, bit for bit."""
+    """The per-encoder stream pipeline (each encoder's forward / backward / SGD on its own stream, weight gradients on
+    another, the head path on the caller's stream, chains overlapping across step boundaries) only reorders independent
+    kernels: parameters, momentum, Pl and losses after 3 steps equal the serialized trainer's, bit for bit."""
     seed, B = 53, 4
     runs = {}
     for ov in (False, True):
