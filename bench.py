@@ -97,7 +97,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="disable the side-stream overlap (serialized kernels)")
+    ap.add_argument("--no-overlap", action="store_true", help="disable the per-encoder stream pipeline (serialized kernels)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with the other conv arithmetic (N=1 only)")
     ap.add_argument("--math", choices=["f32", "split"], default=os.environ.get("MLA_CONV_MATH", "f32"),
                     help="conv forward/dgrad arithmetic: f32 = exact fp32 MFMA; split = exact 3-way bf16 operand split, "
@@ -154,10 +154,9 @@ def main() -> None:
     if rank == 0:
         print(f"[bench] timed region {dt:.3f} s", file=sys.stderr, flush=True)
     loss = float(trainer.losses["loss"].item())
-    # Roofline pass: the same K steps again with HIP events around every conv launch.  In the timed region the later
-    # modality's forward and all weight-gradient GEMMs co-run on a second stream, so a launch's elapsed time there
-    # includes CU sharing; per-kernel durations are therefore taken with the overlap off (kernels serialized),
-    # immediately after the timed region, in this same process.
+    # Roofline pass: the same K steps again with HIP events around every conv / BN call.  In the timed region the encoder
+    # chains co-run on their own streams, so a launch's elapsed time there includes CU sharing; per-kernel durations are
+    # therefore taken with the pipeline off (kernels serialized), immediately after the timed region, in this same process.
     overlapped = trainer.overlap_forward
     trainer.set_overlap(False)
     trainer.train_step(spec, image, label, 0, len_dl)
@@ -249,10 +248,10 @@ def main() -> None:
                          "avg_launch_ms": round(ig["ms"] / max(ig["launches"], 1), 4),
                          "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2),
                          "measured": "HIP events around every conv launch over %d steps run right after the timed region "
-                                     "with the side-stream overlap off (serialized kernels, %.3f ms/step); in the timed "
-                                     "region kernels of two streams share the CUs" % (a.steps, dt_serial / a.steps * 1e3),
+                                     "with the stream pipeline off (serialized, event-instrumented: %.3f ms/step); in the timed "
+                                     "region the encoder chains share the CUs" % (a.steps, dt_serial / a.steps * 1e3),
                          "traffic_source": traffic_src},
-            "overlap": {"side_stream": bool(overlapped), "ms_per_step_serialized": round(dt_serial / a.steps * 1e3, 3),
+            "overlap": {"stream_pipeline": bool(overlapped), "ms_per_step_serialized_instrumented": round(dt_serial / a.steps * 1e3, 3),
                         "conv_tflops_in_timed_region": round(sum(v["work"] for v in summ.values()) / dt / 1e12, 2)},
             "roofline_hbm": hbm_roof,
             "step_vs_t_min": {"t_min_ms": round(t_min_ms, 2), "frac": round(t_min_ms / (dt / a.steps * 1e3), 4),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summaries of bench.py for profiles/: f32 overlapped, f32 serialized, split overlapped.
 export TMPDIR=/tmp
-R=${1:-r01d}
+R=${1:-r01f}
 for V in "f32_overlap:--math f32" "f32_serialized:--math f32 --no-overlap" "split_overlap:--math split" "split_serialized:--math split --no-overlap"; do
   tag=${V%%:*}; args=${V#*:}
   d=gpurun_out/prof_$R/$tag; mkdir -p $d
