@@ -491,6 +491,10 @@ class M3AEClassifier:
         v = self.mae_v.forward(visual)
         return a, v
 
+    def forward_split(self, token: torch.Tensor, padding_mask: torch.Tensor, visual: torch.Tensor):
+        """Per-encoder forward closures in alternation order (for the trainer's per-encoder streams)."""
+        return [lambda: self.mae_a.forward(token, padding_mask), lambda: self.mae_v.forward(visual)]
+
     __call__ = forward
 
     def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
@@ -560,6 +564,10 @@ class Modal3Classifier:
         v = self.mae_v.forward(visual)
         t = self.mae_t.forward(token, padding_mask)
         return a, v, t
+
+    def forward_split(self, token, padding_mask, visual, audio):
+        return [lambda: self.mae_a.forward(audio), lambda: self.mae_v.forward(visual),
+                lambda: self.mae_t.forward(token, padding_mask)]
 
     __call__ = forward
 
