@@ -192,10 +192,16 @@ struct BGemmDesc {
   float alpha;
 };
 
+// Thread -> element maps of the staging loads follow the contiguous dimension of each operand so a wave reads whole
+// 128/256-B pieces whatever the layout: AK = A is k-contiguous (a_k == 1: rows of Q / P / dS), else lanes run along the
+// rows (a_i == 1: the transposed operands P^T, dS^T); BJ = B is column-contiguous (b_j == 1: V, K, Q, dO as [K][N]),
+// else lanes run along k (b_k == 1: K^T, V^T).  The next K step's loads are issued before the MFMAs of the current one.
+template <bool AK, bool BJ>
 __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                      float* __restrict__ C, const BGemmDesc d) {
+  constexpr int LDB = 65;   // odd stride: conflict-free for both store maps and for the MFMA operand reads
   __shared__ __attribute__((aligned(16))) float As[64 * 36];
-  __shared__ float Bs[32 * 64];
+  __shared__ float Bs[32 * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int z = blockIdx.z, b = z / d.H, h = z - b * d.H;
@@ -205,30 +211,35 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A,
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  // A tile element (r, kk): thread -> kk = tid & 31, r = (tid >> 5) + 8 p.  B tile (kk, c): c = tid & 63, kk = (tid >> 6) + 4 p.
-  for (int k0 = 0; k0 < d.K; k0 += 32) {
-    float av[8], bv[8];
+  // A tile element p of this thread: AK: (r = (tid >> 5) + 8 p, kk = tid & 31); else (r = tid & 63, kk = (tid >> 6) + 4 p)
+  // B tile element p:                BJ: (kb = (tid >> 6) + 4 p, c = tid & 63);  else (kb = tid & 31, c = (tid >> 5) + 8 p)
+  float av[8], bv[8];
+  auto load = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int r = i0 + (tid >> 5) + 8 * p, kk = k0 + (tid & 31);
+      const int r = i0 + (AK ? (tid >> 5) + 8 * p : (tid & 63)), kk = k0 + (AK ? (tid & 31) : (tid >> 6) + 4 * p);
       av[p] = (r < d.M && kk < d.K) ? Ab[r * d.a_i + kk * d.a_k] : 0.f;
-      const int kb = k0 + (tid >> 6) + 4 * p, c = j0 + (tid & 63);
+      const int kb = k0 + (BJ ? (tid >> 6) + 4 * p : (tid & 31)), c = j0 + (BJ ? (tid & 63) : (tid >> 5) + 8 * p);
       bv[p] = (kb < d.K && c < d.N) ? Bb[kb * d.b_k + c * d.b_j] : 0.f;
     }
-    __syncthreads();
+  };
+  load(0);
+  for (int k0 = 0; k0 < d.K; k0 += 32) {
+    __syncthreads();            // the previous step's MFMA operand reads are done
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      As[((tid >> 5) + 8 * p) * 36 + (tid & 31)] = av[p];
-      Bs[((tid >> 6) + 4 * p) * 64 + (tid & 63)] = bv[p];
+      As[(AK ? (tid >> 5) + 8 * p : (tid & 63)) * 36 + (AK ? (tid & 31) : (tid >> 6) + 4 * p)] = av[p];
+      Bs[(BJ ? (tid >> 6) + 4 * p : (tid & 31)) * LDB + (BJ ? (tid & 63) : (tid >> 5) + 8 * p)] = bv[p];
     }
     __syncthreads();
+    if (k0 + 32 < d.K) load(k0 + 32);
     const int i = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + i) * 36 + kk * 8 + 4 * hh]);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], Bs[(kk * 8 + 4 * hh + jj) * 64 + wn * 32 + i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], Bs[(kk * 8 + 4 * hh + jj) * LDB + wn * 32 + i], acc, 0, 0, 0);
     }
   }
   float* Cb = C + b * d.c_b + h * d.c_h;
@@ -249,7 +260,13 @@ extern "C" int mla_bgemm(const float* A, const float* B, float* C, int batches, 
   d.a_b = a_strides[0]; d.a_h = a_strides[1]; d.a_i = a_strides[2]; d.a_k = a_strides[3];
   d.b_b = b_strides[0]; d.b_h = b_strides[1]; d.b_k = b_strides[2]; d.b_j = b_strides[3];
   d.c_b = c_strides[0]; d.c_h = c_strides[1]; d.c_i = c_strides[2]; d.c_j = c_strides[3];
-  bgemm_kernel<<<dim3(cdiv(N, 64), cdiv(M, 64), batches * heads), 256, 0, (hipStream_t)stream>>>(A, B, C, d);
+  const dim3 grid(cdiv(N, 64), cdiv(M, 64), batches * heads);
+  hipStream_t st = (hipStream_t)stream;
+  const bool ak = d.a_k == 1 || d.a_i != 1, bj = d.b_j == 1 || d.b_k != 1;   // generic strides use the default maps
+  if (ak && bj) bgemm_kernel<true, true><<<grid, 256, 0, st>>>(A, B, C, d);
+  else if (ak) bgemm_kernel<true, false><<<grid, 256, 0, st>>>(A, B, C, d);
+  else if (bj) bgemm_kernel<false, true><<<grid, 256, 0, st>>>(A, B, C, d);
+  else bgemm_kernel<false, false><<<grid, 256, 0, st>>>(A, B, C, d);
   MLA_CHECK_LAUNCH("bgemm_kernel");
   return MLA_OK;
 }
