@@ -177,6 +177,30 @@ def test_baseline_config0_shapes_bs8():
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("conv_math", ["f32", "split"])
+@pytest.mark.parametrize("B,spec_hw,T,img_hw", [(1, (64, 48), 1, (48, 40)), (5, (130, 70), 2, (70, 50)), (2, (33, 33), 3, (33, 47))])
+def test_step_ragged_shapes_and_batch_one(B, spec_hw, T, img_hw, conv_math):
+    """Edge shapes: batch 1 (BatchNorm statistics over one sample's pixels), one frame, odd / non-multiple-of-32 spatial
+    sizes (every conv, pool and BN kernel on ragged tiles; M far below one workgroup tile in layer4).  One step from
+    identical state against the CPU oracle: features, logits, losses, head gradients, BN running statistics."""
+    seed = 91
+    model, tr, st = build(seed, "as_intended", False, conv_math)
+    spec, image, label = inputs(seed, 0, B, spec_hw, T, img_hw)
+    ref = O.mla_step(st, spec, image, label, 0, 7)
+    losses = tr.train_step(spec.cuda(), image.cuda(), label.cuda(), 0, 7)
+    torch.cuda.synchronize()
+    for k in ("a", "v", "out_a", "out_v"):
+        assert_close(tr.last[k], ref[k], atol=TOL, rtol=1e-4, name=k)
+    for k in ("loss", "loss_a", "loss_v"):
+        assert_close(losses[k].reshape(()), ref[k], atol=TOL, name=k)
+    assert_close(tr.last["head_grad_a_raw"], ref["head_grad_a_raw"], atol=TOL, rtol=1e-4, name="raw head grad a")
+    assert_close(model.fusion_module.fc_out.weight_grad, ref["head_grad_v"], atol=TOL, rtol=1e-4, name="projected head grad v")
+    sd = model.state_dict()
+    for enc, params in (("audio_net", st.audio), ("visual_net", st.visual)):
+        for k in ("bn1.running_mean", "bn1.running_var", "layer4.1.bn2.running_mean", "layer4.1.bn2.running_var"):
+            assert_close(sd[f"{enc}.{k}"], params[k], atol=1e-5, rtol=1e-4, name=f"{enc}.{k}")
+
+
 def test_adjoint_identities_full_size():
     """Size-independent property at the CREMA-D layer shapes (B=64): <dY, conv(X,W)> = <dgrad(dY), X> =
     <wgrad(X,dY), W>.  Exercises the three conv kernels at BASELINE.json's full sizes without a CPU oracle."""
