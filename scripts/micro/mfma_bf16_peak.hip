@@ -1,6 +1,7 @@
 // Calibration: sustained v_mfma_f32_32x32x16_bf16 rate with no memory traffic, NACC independent accumulators per wave.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+// build: hipcc --offload-arch=gfx950 -O3 mfma_bf16_peak.hip -o mfma_bf16_peak
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
