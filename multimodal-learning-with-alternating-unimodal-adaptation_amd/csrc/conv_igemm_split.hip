@@ -228,7 +228,10 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
   // a second register set with the loads of tile it+2 pinned at the top of step it: 3-7 % slower, unpinned with a
   // two-stage load distance: +2 % on the K >= 1152 layers, -4 % on the stride-2 parity classes; a ring of three
   // LDS buffers with the next step's first-half fragments fetched before the barrier: +-0; plane-wise fragment reads
-  // issued one MFMA group ahead of their use, with and without sched_group_barrier pinning: +-1 %.  Timing-only ablations:
+  // issued one MFMA group ahead of their use, with and without sched_group_barrier pinning: +-1 %; a hand-scheduled
+  // inline-asm stage (all 18 fragment reads in flight, counted lgkmcnt waits, fixed registers) with SIMD partners
+  // staging in opposite halves of the step: -15 % -- what pays is VALU / LDS work inside the MFMA shadows of the SAME
+  // wave, which the compiler's interleaved schedule already gives.  Timing-only ablations:
   // MFMAs alone reach the 6-product ceiling (333 TF at the sustained bf16 rate) once the tail of the last round is
   // taken out; adding the fragment reads costs ~20 %, the barrier nothing, staging another ~17 %; a tile's
   // prologue / epilogue are exposed with one workgroup per CU (~10 us per tile round on the 1x1 convs).
