@@ -46,6 +46,8 @@ int mla_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, v
 /* Implicit-GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
  * bn_partial (nullable): if given, the epilogue also writes per-M-tile column sums and sums of
  * squares of y, layout [tiles][2][Cout]; *bn_tiles receives `tiles`.  Feed to mla_bn_finalize. */
+/* measurement hook: force the fp32 kernels' tile 0..3 (128x128, 256x64, 64x64, 128x64) where Cout allows; -1 = automatic */
+int mla_conv2d_f32_cfg(int cfg);
 size_t mla_conv2d_fwd_partial_elems(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mla_conv2d_fwd(const float* x, const float* w_hwio, float* y,
                    int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,

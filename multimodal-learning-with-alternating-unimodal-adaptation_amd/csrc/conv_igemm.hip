@@ -10,7 +10,7 @@
 // dy=kh-pad; dgrad uses the per-tap transposed weights and, for stride 2, one geometry per output
 // parity class (no MFMA work on structurally-zero taps), one launch per class.
 //
-// Tiling: 256 threads = 4 waves; block tile BMxBN (128x128, 256x64 or 64x64, picked per problem to
+// Tiling: 256 threads = 4 waves; block tile BMxBN (128x128, 256x64, 128x64 or 64x64, picked per problem to
 // minimise the tail on 256 CUs), K step 32 channels of one tap; A (pixels x channels) and B
 // (channels x cout) staged through LDS with register prefetch of the next K step; every wave owns a
 // (BM/WM)x(BN/WN) sub-tile as 32x32 MFMA tiles.  fp32 MFMA moves 512 B of LDS per 64-cycle
@@ -407,6 +407,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // host side
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t mla_bn_partial_scratch_elems(int C);   // bn.hip: scratch tail every BN partial buffer carries
+int g_f32_cfg = -1;
+extern "C" int mla_conv2d_f32_cfg(int cfg) { g_f32_cfg = (cfg >= 0 && cfg < CFG_COUNT) ? cfg : -1; return g_f32_cfg; }
+
 static int launch_igemm(const float* X, const float* Wt, float* Y, const float* R, const float* MASK, float* part,
                         const IGemmGeom& mg, bool scalar, int cfg, hipStream_t st, const float* BIAS = nullptr,
                         float* Y2 = nullptr) {
@@ -419,6 +422,8 @@ static int launch_igemm(const float* X, const float* Wt, float* Y, const float* 
     igemm_kernel<128, 128, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   } else if (cfg == CFG_256x64) {
     igemm_kernel<256, 64, 4, 1, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
+  } else if (cfg == CFG_128x64) {
+    igemm_kernel<128, 64, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   } else {
     igemm_kernel<64, 64, 2, 2, false><<<total, 256, 0, st>>>(X, Wt, Y, R, MASK, part, BIAS, Y2, mg);
   }

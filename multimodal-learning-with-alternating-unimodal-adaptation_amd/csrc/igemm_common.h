@@ -173,19 +173,25 @@ static inline int check_conv(const char* who, int N, int H, int W, int Cin, int 
 
 // Tile choice: every CU runs ceil(blocks/256) rounds of MFMA-bound tiles, so minimise
 // rounds * tile area / efficiency (the 64x64 tile pays more barriers per flop).
-enum { CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2 };
-static inline int cfg_bm(int cfg) { return cfg == CFG_128x128 ? 128 : (cfg == CFG_256x64 ? 256 : 64); }
+enum { CFG_128x128 = 0, CFG_256x64 = 1, CFG_64x64 = 2, CFG_128x64 = 3, CFG_COUNT = 4 };
+static inline int cfg_bm(int cfg) { return (cfg == CFG_128x128 || cfg == CFG_128x64) ? 128 : (cfg == CFG_256x64 ? 256 : 64); }
 static inline int cfg_bn(int cfg) { return cfg == CFG_128x128 ? 128 : 64; }
 
+#ifndef F32_EFF
+#define F32_EFF 0.93, 0.90, 1.0, 1.02
+#endif
+extern int g_f32_cfg;   // measurement hook (conv_igemm.hip): force one tile
 static inline int pick_cfg(const long* Ms, const int* weights, int n, int CO, bool scalar) {
   if (scalar) return CFG_64x64;   // stem: 2-5 K steps per block, so many small resident blocks overlap best (measured -12 % vs 256x64)
-  // measured on the ResNet-18 layer shapes (scripts/bench_conv.py): the 64x64 tile reaches 0.97 of the big
-  // tiles' per-flop rate, and any tile loses ~10 % when fewer than two workgroups are resident per CU.
-  const double eff[3] = {1.0, 1.0, 0.97};
+  // per-flop rates at full rounds, measured on the ResNet-18 layer shapes (scripts/f32_tile_probe.py), relative to the
+  // 64x64 tile: 128x128 0.93, 256x64 0.90, 128x64 1.02 (a.l1: 124.6 vs 112.9 TF on 256x64); any tile loses ~10 % when
+  // fewer than two workgroups are resident per CU.
+  const double eff[CFG_COUNT] = {F32_EFF};
   int best = -1;
   double best_cost = 0;
-  for (int cfg = 0; cfg < 3; ++cfg) {
-    if (CO % cfg_bn(cfg) != 0) continue;
+  if (g_f32_cfg >= 0 && CO % cfg_bn(g_f32_cfg) == 0) return g_f32_cfg;
+  for (int cfg = 0; cfg < CFG_COUNT; ++cfg) {
+    if (CO % cfg_bn(cfg) != 0 || eff[cfg] <= 0.0) continue;
     double blocks = 0, wsum = 0, wblocks = 0;
     for (int k = 0; k < n; ++k) {
       const double b = (double)cdiv(Ms[k], cfg_bm(cfg)) * (CO / cfg_bn(cfg));

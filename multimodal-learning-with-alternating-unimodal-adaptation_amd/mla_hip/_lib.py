@@ -26,6 +26,7 @@ PROTOTYPES = {
     "mla_video_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mla_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mla_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mla_conv2d_f32_cfg": (_I, [_I]),
     "mla_conv2d_fwd_partial_elems": (_Z, [_I] * 9),
     "mla_conv2d_fwd": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
     "mla_conv2d_dgrad": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P]),

@@ -93,6 +93,11 @@ def nhwc_to_nchw(src: torch.Tensor, stream: Optional[int] = None) -> torch.Tenso
 
 
 # ---- convolution --------------------------------------------------------------------------------
+def conv2d_f32_cfg(cfg: int = -1) -> int:
+    """Measurement hook: force the fp32 conv kernels' tile (0..3) or restore the automatic choice (-1)."""
+    return int(_lib.load().mla_conv2d_f32_cfg(int(cfg)))
+
+
 def conv2d_fwd_partial_elems(N, H, W, Cin, Cout, KH, KW, stride, pad) -> int:
     return int(_lib.load().mla_conv2d_fwd_partial_elems(N, H, W, Cin, Cout, KH, KW, stride, pad))
 

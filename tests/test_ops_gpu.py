@@ -184,6 +184,29 @@ def test_conv_split_is_not_reduced_precision(ops):
         assert rms(e3) > 3 * rms(es), "bf16x3 should be measurably less accurate than the six-product split"
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3], ids=lambda c: f"f32tile{c}")
+def test_conv_f32_every_tile(ops, cfg):
+    """Every fp32 tile (128x128, 256x64, 64x64, 128x64) forced on a ragged problem: forward + input gradient parity."""
+    N, H, W, Cin, Cout, k, s, p = 2, 33, 17, 128, 128, 3, 1, 1
+    seed = 123 + cfg
+    x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
+    w = O.portable_normal(seed, (Cout, Cin, k, k), stream=2, std=math.sqrt(2.0 / (Cin * k * k)))
+    y_ref = O.conv2d_fwd(x, w, s, p)
+    dy = O.portable_normal(seed, tuple(y_ref.shape), stream=3)
+    xd, wd, dyd = nhwc(x).cuda(), hwio(w).cuda(), nhwc(dy).cuda()
+    ops.conv2d_f32_cfg(cfg)
+    try:
+        part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, k, k, s, p), device="cuda")
+        y, tiles = ops.conv2d_fwd(xd, wd, s, p, bn_partial=part)
+        assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="conv fwd")
+        pt = part[:tiles * 2 * Cout].view(tiles, 2, Cout).double().sum(0).cpu()
+        assert_close(pt[0], y_ref.double().sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="fused colsum")
+        dx = ops.conv2d_dgrad(dyd, wd, (N, H, W, Cin), s, p, torch.empty(w.numel(), device="cuda"))
+        assert_close(nchw(dx.cpu()), O.conv2d_dgrad(dy, w, x.shape, s, p), atol=0, rtol=2e-5, name="conv dgrad")
+    finally:
+        ops.conv2d_f32_cfg(-1)
+
+
 def test_conv_rejects_bad_shapes(ops):
     from mla_hip import MLAHipError
     x = torch.zeros((1, 8, 8, 48), device="cuda")
