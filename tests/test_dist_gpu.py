@@ -1,0 +1,90 @@
+"""GPU, world_size 2: the REAL MLATrainer data-parallel step (mla_hip/trainer.py + dist.py), two processes sharing the
+one GPU of the test box over the `gloo` backend (it accepts device tensors; RCCL refuses two ranks on one device).
+Everything but the transport is the production path: per-encoder streams, bucketed asynchronous all-reduce of the flat
+encoder gradients, the packed head exchange, GSPlugin on the globally averaged feature, identical head update on every
+rank.  Expected result = the reference's DataParallel semantics (main.py:732), computed by the CPU oracle in
+tests/test_dist_gloo.py: per-replica BatchNorm statistics, head + CE + projection on the global batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mla_oracle as O  # noqa: E402
+from test_dist_gloo import B_GLOBAL, SEED, WORLD, _inputs, _reference_dataparallel  # noqa: E402
+from util import assert_close, assert_close_robust  # noqa: E402
+
+
+def _worker(rank, port, outdir, conv_math):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    from mla_hip import AVClassifier, Comm, MLATrainer
+
+    class Args:
+        fusion_method, dataset, gs_flag, modulation = "concat", "CREMAD", True, "Normal"
+
+    model = AVClassifier(Args(), seed=0, conv_math=conv_math)
+    pa, pv = O.make_resnet18_params("audio", SEED), O.make_resnet18_params("visual", SEED + 1)
+    hd = O.make_head_params(512, 6, SEED + 2)
+    sd = {f"audio_net.{k}": v for k, v in pa.items()}
+    sd.update({f"visual_net.{k}": v for k, v in pv.items()})
+    sd.update({f"fusion_module.fc_out.{k}": v for k, v in hd.items()})
+    model.load_state_dict(sd)
+    comm = Comm(bucket_bytes=1 << 20)                       # several async buckets per encoder
+    assert comm.active and comm.world == WORLD
+    tr = MLATrainer(model, lr=1e-3, momentum=0.9, weight_decay=1e-4, gs_mode="as_intended", comm=comm)
+    tr.keep_debug = True
+    spec, image, label = _inputs()
+    per = B_GLOBAL // WORLD
+    sl = slice(rank * per, (rank + 1) * per)
+    losses = tr.train_step(spec[sl].cuda(), image[sl].cuda(), label[sl].cuda(), 0, 10)
+    torch.cuda.synchronize()
+    res = {"loss_a": losses["loss_a"].cpu(), "loss_v": losses["loss_v"].cpu(),
+           "dW_a": tr.last["head_grad_a"].cpu(), "dW_v": model.fusion_module.fc_out.weight_grad.cpu().clone(),
+           "db_v": model.fusion_module.fc_out.bias_grad.cpu().clone() if hasattr(model.fusion_module.fc_out, "bias_grad") else None,
+           "Pl": tr.gs_plugin.Pl.cpu(), "head_w": model.fusion_module.fc_out.weight.cpu().clone()}
+    if rank == 0:
+        res["grads_a"] = {k: v.cpu() for k, v in model.audio_net.grads_as_reference().items()}
+        res["grads_v"] = {k: v.cpu() for k, v in model.visual_net.grads_as_reference().items()}
+    torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("conv_math", ["f32", "split"])
+def test_two_rank_trainer_equals_dataparallel_semantics(tmp_path, conv_math):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, str(tmp_path), conv_math)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    ref = _reference_dataparallel()
+    assert_close(r0["loss_a"].reshape(()), ref["a"]["loss"], atol=2e-4, name="global loss a")
+    assert_close(r0["loss_v"].reshape(()), ref["v"]["loss"], atol=2e-4, name="global loss v")
+    assert_close(r0["dW_a"], ref["a"]["dW"], atol=2e-4, name="head grad a (global batch)")
+    assert_close(r0["dW_v"], ref["v"]["dW"], atol=2e-4, name="projected head grad v (global batch)")
+    assert_close(r0["Pl"], ref["Pl"], atol=1e-6, rtol=1e-4, name="Pl")
+    for k in ("dW_a", "dW_v", "Pl", "head_w", "loss_a", "loss_v"):
+        assert torch.equal(r0[k], r1[k]), f"ranks must hold identical {k}"
+    for enc in ("a", "v"):
+        for k, g in ref[enc]["grads"].items():
+            assert_close_robust(r0["grads_" + enc][k], g, rel_l2=5e-2, elem_tol=1.0, frac=0.0, name=f"reduced grad {enc}.{k}")
