@@ -112,11 +112,18 @@ def main() -> None:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("MLA_DIST_BACKEND", "nccl")      # "gloo": rehearse N ranks on a box with fewer GPUs than ranks
+    if world > ndev and backend == "nccl":
+        sys.exit(f"bench.py: {world} ranks but {ndev} GPU(s): RCCL needs one device per rank")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)        # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)    # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from mla_hip import AVClassifier, Comm, MLATrainer, ops
 
