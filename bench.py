@@ -214,10 +214,11 @@ def main() -> None:
         kname = ("igemm_split_kernel (conv forward + input gradient, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; "
                  "peak = bf16 MFMA rate / 6)") if split else "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)"
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
-        if os.path.exists(tpath) and not split:     # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, per launch
+        tpath = os.path.join(ROOT, "profiles", "r01f_igemm_traffic.json")
+        if os.path.exists(tpath):     # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, per conv call
             tj = json.load(open(tpath))
-            traffic, traffic_src = round(tj["hbm_bytes_per_launch"]), "profiles/r01_igemm_traffic.json: " + tj["method"]
+            traffic = round(tj["split" if split else "f32"]["hbm_bytes_per_call"])
+            traffic_src = "profiles/r01f_igemm_traffic.json: " + tj["method"] + "; " + tj["note"]
         per_kind = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
                         "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items() if k.startswith("conv")}
         # HBM family: BatchNorm forward / backward against 8 TB/s; `achieved` = algorithmic bytes / time
