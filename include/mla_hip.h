@@ -137,6 +137,19 @@ int mla_head_ce_fwd_bwd(const float* X, const float* W, const float* b, const in
                         float* logits, float* loss, float* dW, float* db, float* dX, float* ws,
                         int B, int D, int C, float inv_batch, void* stream);
 
+/* The same head where autograd splits it, for the nn.Module / autograd.Function protocol (main.py:432-435 executed
+ * literally: `out = fc_out(a)`; `loss = criterion(out, label)`; `loss.backward()`):
+ *   mla_ce_fwd_bwd   nn.CrossEntropyLoss() (main.py:130), mean reduction: loss and dlogits = (softmax - onehot) * inv_batch
+ *                    in one pass; ws: B floats.  A label outside [0, C) yields a NaN loss (the reference asserts).
+ *   mla_head_bwd     autograd of nn.Linear (fusion_modules.py:19) for a given dlogits: dW = s dlogits^T X, db = s sum dlogits,
+ *                    dX = s dlogits W  (s = 1/world under data parallel, else 1).
+ *   mla_scale_by_device_scalar   x *= *scalar, the scalar read on the device (gradient flowing into a loss node). */
+int mla_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* ws,
+                   int B, int C, float inv_batch, void* stream);
+int mla_head_bwd(const float* X, const float* W, const float* dlogits, float* dW, float* db, float* dX,
+                 int B, int D, int C, float scale, void* stream);
+int mla_scale_by_device_scalar(float* x, const float* scalar, size_t n, void* stream);
+
 /* ---- GSPlugin.before_update (utils/utils.py:24-41) ------------------------------------------- */
 /* r[j] = scale * sum_i X[i][j]   (column mean with scale = 1/B; rank-local column sum otherwise) */
 int mla_colsum(const float* X, float* r, int B, int D, float scale, void* stream);

@@ -31,11 +31,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   const float m = wave_max(fmaxf(l0, l1));
   const float e0 = lane < C ? expf(l0 - m) : 0.f, e1 = lane + 64 < C ? expf(l1 - m) : 0.f;
   const float s = wave_sum(e0 + e1);
-  const int lab = (int)labels[row];
+  const long lab_raw = (long)labels[row];
+  const bool lab_ok = lab_raw >= 0 && lab_raw < C;   // out of range: NaN loss (the reference's CE kernel asserts), no OOB LDS read
+  const int lab = lab_ok ? (int)lab_raw : 0;
   const float lse = m + logf(s);
   if (lane < C) logits[(size_t)row * C + lane] = l0;
   if (lane + 64 < C) logits[(size_t)row * C + lane + 64] = l1;
-  if (lane == 0) rowloss[row] = (lse - lg[wave][lab]) * inv_batch;
+  if (lane == 0) rowloss[row] = lab_ok ? (lse - lg[wave][lab]) * inv_batch : NAN;
   __builtin_amdgcn_wave_barrier();
   const float d0 = (e0 / s - (lane == lab ? 1.f : 0.f)) * inv_batch;
   const float d1 = (e1 / s - (lane + 64 == lab ? 1.f : 0.f)) * inv_batch;
@@ -93,6 +95,97 @@ extern "C" int mla_head_ce_fwd_bwd(const float* X, const float* W, const float* 
   MLA_CHECK_LAUNCH("head_fwd_kernel");
   head_grad_kernel<<<dim3(cdiv(D, 256), C), 256, 0, st>>>(X, dlogits, rowloss, dW, db, loss, B, D, C);
   MLA_CHECK_LAUNCH("head_grad_kernel");
+  return MLA_OK;
+}
+
+// ---- autograd-protocol entry points: the same head, split where autograd splits it (main.py:432-435) -------------
+// nn.CrossEntropyLoss (mean) forward + d logits in one launch: one wave per sample.  A label outside [0, C) poisons
+// the loss with NaN (the reference's CUDA kernel asserts); its d logits row is zero.
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                          float* __restrict__ rowloss, float* __restrict__ dlogits, int B, int C,
+                                                          float inv_batch) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= B) return;
+  const float* l = logits + (size_t)row * C;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, l[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(l[c] - m);
+  s = wave_sum(s);
+  const long lab = (long)labels[row];
+  const bool ok = lab >= 0 && lab < C;
+  if (lane == 0) rowloss[row] = ok ? (m + logf(s) - l[lab]) * inv_batch : NAN;
+  for (int c = lane; c < C; c += 64)
+    dlogits[(size_t)row * C + c] = ok ? (expf(l[c] - m) / s - (c == lab ? 1.f : 0.f)) * inv_batch : 0.f;
+}
+__global__ __launch_bounds__(64) void sum_to_scalar_kernel(const float* __restrict__ v, float* __restrict__ out, int n) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) a += v[i];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) *out = a;
+}
+extern "C" int mla_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits, float* ws, int B, int C,
+                              float inv_batch, void* stream) {
+  MLA_REQUIRE(logits && labels && loss && dlogits && ws && B > 0 && C > 0, "mla_ce_fwd_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  ce_fwd_bwd_kernel<<<cdiv(B, 4), 256, 0, st>>>(logits, labels, ws, dlogits, B, C, inv_batch);
+  MLA_CHECK_LAUNCH("ce_fwd_bwd_kernel");
+  sum_to_scalar_kernel<<<1, 64, 0, st>>>(ws, loss, B);
+  MLA_CHECK_LAUNCH("sum_to_scalar_kernel");
+  return MLA_OK;
+}
+
+// nn.Linear backward from an arbitrary d logits (autograd hands it over): dX = scale * dl W (wave per sample),
+// dW = scale * dl^T X, db = scale * colsum(dl).  scale = 1/world under data parallel.
+__global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ dlogits, const float* __restrict__ W,
+                                                       float* __restrict__ dX, int B, int D, int C, float scale) {
+  const int d = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+  if (d >= D) return;
+  float a = 0.f;
+  for (int c = 0; c < C; ++c) a += dlogits[(size_t)row * C + c] * W[(size_t)c * D + d];
+  dX[(size_t)row * D + d] = a * scale;
+}
+__global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ X, const float* __restrict__ dlogits,
+                                                       float* __restrict__ dW, float* __restrict__ db, int B, int D, int C,
+                                                       float scale) {
+  const int c = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  if (d < D) {
+    float a = 0.f;
+    for (int r = 0; r < B; ++r) a += dlogits[(size_t)r * C + c] * X[(size_t)r * D + d];
+    dW[(size_t)c * D + d] = a * scale;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    float a = 0.f;
+    for (int r = threadIdx.x; r < B; r += 64) a += dlogits[(size_t)r * C + c];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) db[c] = a * scale;
+  }
+}
+extern "C" int mla_head_bwd(const float* X, const float* W, const float* dlogits, float* dW, float* db, float* dX, int B, int D,
+                            int C, float scale, void* stream) {
+  MLA_REQUIRE(X && W && dlogits && dW && db && dX && B > 0 && D > 0 && C > 0, "mla_head_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  head_dx_kernel<<<dim3(cdiv(D, 256), B), 256, 0, st>>>(dlogits, W, dX, B, D, C, scale);
+  MLA_CHECK_LAUNCH("head_dx_kernel");
+  head_dw_kernel<<<dim3(cdiv(D, 256), C), 256, 0, st>>>(X, dlogits, dW, db, B, D, C, scale);
+  MLA_CHECK_LAUNCH("head_dw_kernel");
+  return MLA_OK;
+}
+
+// x[i] *= *scalar (the scalar lives on the device: the gradient autograd passes into a loss node)
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, const float* __restrict__ s, size_t n) {
+  const float f = *s;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= f;
+}
+extern "C" int mla_scale_by_device_scalar(float* x, const float* scalar, size_t n, void* stream) {
+  MLA_REQUIRE(x && scalar, "mla_scale_by_device_scalar: null pointer");
+  if (n == 0) return MLA_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  scale_dev_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x, scalar, n);
+  MLA_CHECK_LAUNCH("scale_dev_kernel");
   return MLA_OK;
 }
 
@@ -295,7 +388,12 @@ __global__ __launch_bounds__(256) void eval_fuse_kernel(const EvalFuseArgs a, co
   __syncthreads();
   if (tid < a.M && weights_out) weights_out[tid] = wgt[tid];
   for (int r = tid; r < a.B; r += 256) {               // one sample per thread: arg-max (first maximum, like np.argmax)
-    const int lab = (int)labels[r];
+    const long lab_raw = (long)labels[r];
+    if (lab_raw < 0 || lab_raw >= a.C) {               // never index the counters with a bad label; poison the weights instead
+      if (weights_out) weights_out[0] = NAN;
+      continue;
+    }
+    const int lab = (int)lab_raw;
     atomicAdd(&counts[lab], 1);
     float best = -INFINITY;
     int arg = 0;

@@ -11,4 +11,6 @@ from .model import AVClassifier, ConcatFusion, SharedHead  # noqa: F401
 from .m3ae import ConcatFusion3, M3AEClassifier, M3AEEncoder, Modal3Classifier  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .plugin import GSPlugin  # noqa: F401
+from .protocol import CrossEntropyLoss, DataParallel, setup_seed, weight_init  # noqa: F401
 from .trainer import Evaluator, MLATrainer  # noqa: F401
+from . import torch_ops  # noqa: F401,E402  registers torch.ops.mla_hip.* (dispatch key CUDA; no other implementation)

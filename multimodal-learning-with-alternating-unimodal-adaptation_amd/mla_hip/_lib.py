@@ -54,6 +54,9 @@ PROTOTYPES = {
     "mla_avgpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mla_head_ws_elems": (_Z, [_I, _I]),
     "mla_head_ce_fwd_bwd": (_I, [_P] * 10 + [_I, _I, _I, _F, _P]),
+    "mla_ce_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "mla_head_bwd": (_I, [_P] * 6 + [_I, _I, _I, _F, _P]),
+    "mla_scale_by_device_scalar": (_I, [_P, _P, _Z, _P]),
     "mla_colsum": (_I, [_P, _P, _I, _I, _F, _P]),
     "mla_gs_ws_elems": (_Z, [_I, _I]),
     "mla_gs_project": (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),

@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, group=None, bucket_bytes: int = 16 << 20, force: bool = False):
+    def __init__(self, group=None, bucket_bytes: int = 16 << 20, force: bool = False, dedicated_head_group: bool = True):
         """force=True issues every collective even with a single rank (used to rehearse the RCCL path on
         a one-GPU box); results are unchanged because SUM over one rank is the identity."""
         self.group = group
@@ -32,6 +32,12 @@ class Comm:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.active = (self.world > 1) or (force and dist.is_initialized())
+        # The head path is latency-critical and must not queue behind the 44.7 MB encoder-gradient buckets: it
+        # gets its own communicator (own RCCL stream).  new_group is collective: every rank builds its Comm at the same point.
+        self.head_group = group
+        if self.active and dedicated_head_group:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            self.head_group = dist.new_group(ranks=ranks)
 
     # ---- encoder gradients ------------------------------------------------------------------
     def allreduce_flat_async(self, flat: torch.Tensor) -> List:
@@ -60,10 +66,23 @@ class Comm:
         msg[:n0].copy_(head_grad_flat)
         msg[n0:n0 + n1].copy_(colsum)
         msg[n0 + n1:].copy_(loss.reshape(1))
-        dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=self.head_group)
         head_grad_flat.copy_(msg[:n0])
         colsum.copy_(msg[n0:n0 + n1])
         loss.reshape(1).copy_(msg[n0 + n1:])
+
+    def allreduce_small(self, t: torch.Tensor) -> None:
+        """Blocking in-place SUM of a small critical-path message (packed dW|db, feature mean) on the head communicator."""
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.head_group)
+
+    def allgather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """(B_local, C) -> (world * B_local, C) in rank order (evaluation under --dynamic needs global-batch logits, Q9)."""
+        if not self.active:
+            return t
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.head_group)
+        return out
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> None:
         if self.active:

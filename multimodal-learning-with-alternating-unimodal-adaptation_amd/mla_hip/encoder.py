@@ -25,6 +25,7 @@ import torch
 
 from . import ops
 from ._lib import MLAHipError
+from .module import BatchNorm2dHolder, Conv2dHolder, FlatModule
 
 
 def conv_specs(modality: str) -> List[Tuple[str, int, int, int, int, int]]:
@@ -53,10 +54,15 @@ def bn_name_for_conv(conv_name: str) -> str:
     return conv_name.replace("conv", "bn")
 
 
-class ResNet18Encoder:
-    """ResNet-18 trunk without avgpool/fc (backbone.py:96-99), training-mode BatchNorm."""
+class ResNet18Encoder(FlatModule):
+    """ResNet-18 trunk without avgpool/fc (backbone.py:96-99), training-mode BatchNorm.
+
+    nn.Module face (module.py): `named_parameters()` / `state_dict()` yield the reference's names in the reference's
+    registration order (conv1, bn1, layer1.0.conv1, ... backbone.py:78-95, 27-33) with OIHW conv weights that are
+    strided views of the flat HWIO buffer; leaves are nn.Conv2d / nn.BatchNorm2d instances for `weight_init`."""
 
     def __init__(self, modality: str, device="cuda", seed: Optional[int] = None, conv_math: Optional[str] = None):
+        super().__init__()
         self.modality = modality
         self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", "f32")
         if self.conv_math not in ("f32", "split"):
@@ -132,6 +138,18 @@ class ResNet18Encoder:
         # Stream that carries this encoder's training chain (set by MLATrainer): anything that touches the encoder from
         # another stream first waits for it (stream-ordered semantics for forward / state_dict / eval without a device sync).
         self.tail_stream: Optional[torch.cuda.Stream] = None
+        # ---- reference-named parameter / buffer tree (views; nothing is copied)
+        for name, _cin, _cout, _k, s_, p_ in self.specs:
+            w = self._param_view(self.p[name + ".weight"], self.g[name + ".weight"], lambda t: t.permute(3, 2, 0, 1), name + ".weight")
+            parent, leaf = self._descend(self, name)
+            parent.add_module(leaf, Conv2dHolder(w, s_, p_))
+            bn = bn_name_for_conv(name)
+            bw = self._param_view(self.p[bn + ".weight"], self.g[bn + ".weight"], lambda t: t, bn + ".weight")
+            bb = self._param_view(self.p[bn + ".bias"], self.g[bn + ".bias"], lambda t: t, bn + ".bias")
+            parent, leaf = self._descend(self, bn)
+            parent.add_module(leaf, BatchNorm2dHolder(bw, bb, self.rm[bn], self.rv[bn]))
+        self.register_state_dict_pre_hook(ResNet18Encoder._before_state_dict)
+        self.register_load_state_dict_post_hook(ResNet18Encoder._after_load_state_dict)
         self.reset_parameters(seed)
 
     def _await_tail(self) -> None:
@@ -144,6 +162,7 @@ class ResNet18Encoder:
     # ------------------------------------------------------------------------------------------
     # parameters / state_dict (reference keys and OIHW layout at the boundary)
     # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
     def reset_parameters(self, seed: Optional[int] = None) -> None:
         """utils/utils.py:106-114 weight_init (overrides backbone.py:101-106): kaiming-normal fan_out, BN 1/0."""
         gen = torch.Generator(device="cpu")
@@ -159,44 +178,28 @@ class ResNet18Encoder:
             self.p[bn + ".weight"].fill_(1.0)
             self.p[bn + ".bias"].zero_()
 
-    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
-        self._await_tail()
-        sd = {}
-        for name, *_ in self.specs:
-            sd[prefix + name + ".weight"] = self.p[name + ".weight"].permute(3, 2, 0, 1).contiguous()
-            bn = bn_name_for_conv(name)
-            sd[prefix + bn + ".weight"] = self.p[bn + ".weight"].clone()
-            sd[prefix + bn + ".bias"] = self.p[bn + ".bias"].clone()
-            sd[prefix + bn + ".running_mean"] = self.rm[bn].clone()
-            sd[prefix + bn + ".running_var"] = self.rv[bn].clone()
-            sd[prefix + bn + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked[bn], dtype=torch.int64)
-        # reference module order: conv, bn pairs
-        return sd
+    def _bn_module(self, bn: str):
+        m = self
+        for part in bn.split("."):
+            m = m._modules[part]
+        return m
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
+    @staticmethod
+    def _before_state_dict(self, prefix, keep_vars) -> None:
+        """state_dict() hook: stream-order after the encoder's training chain; materialise the BN call counters."""
         self._await_tail()
-        for name, *_ in self.specs:
-            keys = [name + ".weight"]
-            bn = bn_name_for_conv(name)
-            keys += [bn + ".weight", bn + ".bias", bn + ".running_mean", bn + ".running_var"]
-            for k in keys:
-                if prefix + k not in sd:
-                    if strict:
-                        raise KeyError(f"missing key {prefix + k}")
-                    continue
-                t = sd[prefix + k].to(device=self.device, dtype=torch.float32)
-                if k == name + ".weight":
-                    self.p[k].copy_(t.permute(2, 3, 1, 0))       # OIHW -> HWIO
-                    self._wsplit_dirty = True
-                elif k.endswith("running_mean"):
-                    self.rm[bn].copy_(t)
-                elif k.endswith("running_var"):
-                    self.rv[bn].copy_(t)
-                else:
-                    self.p[k].copy_(t)
-            nbt = sd.get(prefix + bn + ".num_batches_tracked")
-            if nbt is not None:
-                self.num_batches_tracked[bn] = int(nbt)
+        for bn in self.bn_names:
+            self._bn_module(bn).num_batches_tracked.fill_(self.num_batches_tracked[bn])
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        self._await_tail()                                   # the copies below must not race the training chain
+        self._wsplit_dirty = True
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    @staticmethod
+    def _after_load_state_dict(self, incompatible_keys) -> None:
+        for bn in self.bn_names:
+            self.num_batches_tracked[bn] = int(self._bn_module(bn).num_batches_tracked)
 
     def grads_as_reference(self) -> Dict[str, torch.Tensor]:
         """Gradients keyed/laid out like the reference's named_parameters() (OIHW)."""
@@ -293,15 +296,12 @@ class ResNet18Encoder:
 
     def train(self, mode: bool = True):
         """nn.Module.train/eval semantics for the BatchNorm layers: eval uses the running statistics."""
+        super().train(mode)
         self._await_tail()
-        self.training = bool(mode)
         self._wsplit_dirty = True
         if not self.training:
             ops.bn_invstd(self.running[self._tot_bn:], self._rinv_flat)       # one launch for all 20 BN layers
         return self
-
-    def eval(self):
-        return self.train(False)
 
     def _conv_bn(self, ws, st, x, conv_name, stride, pad, y, out, relu, residual=None):
         """y = conv(x); BN statistics fused in the conv epilogue; out = [relu](bn(y) [+ residual])."""

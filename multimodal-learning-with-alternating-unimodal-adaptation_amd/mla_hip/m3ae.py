@@ -18,9 +18,12 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
+import torch.nn as nn
 
 from . import ops
 from ._lib import MLAHipError
+from .model import ConcatFusion, N_CLASSES, SharedHead, _Classifier
+from .module import FlatModule, Holder
 
 
 def _sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:                      # m3ae.py:181-194
@@ -45,7 +48,11 @@ def sincos_pos_embed(embed_dim: int, length: int, two_d: bool) -> torch.Tensor:
     return torch.from_numpy(emb.astype(np.float32))
 
 
-class M3AEEncoder:
+class M3AEEncoder(FlatModule):
+    """nn.Module face (module.py): parameters under the reference's names, order and layouts -- nn.Linear weights
+    (out, in) as transposed views of the [in][out] GEMM operands, type embeddings / cls as (1,1,D) -- registered as
+    MaskedMultimodalAutoencoder does (direct parameters, text_embedding, image_embedding, encoder: m3ae.py:305-331)
+    resp. the audio branch of CAVMAEFT (cav_mae.py:116-145)."""
     BLOCK_PARAMS = [("layer_norm1.weight", "D"), ("layer_norm1.bias", "D"), ("attention.qkv_linear.weight", "D,3D"),
                     ("attention.qkv_linear.bias", "3D"), ("attention.fc.weight", "D,D"), ("attention.fc.bias", "D"),
                     ("layer_norm2.weight", "D"), ("layer_norm2.bias", "D"), ("transformer_mlp.fc1.weight", "D,4D"),
@@ -55,6 +62,7 @@ class M3AEEncoder:
                  text_vocab_size: int = 30522, patch_dim: int = 768, seed: Optional[int] = None, conv_math: Optional[str] = None):
         if kind not in ("text", "image", "audio"):
             raise ValueError("kind must be 'text', 'image' or 'audio'")
+        super().__init__()
         self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", "f32")     # arithmetic of the Linear GEMMs (encoder.py)
         if self.conv_math not in ("f32", "split"):
             raise MLAHipError(f"conv_math must be 'f32' or 'split', got {self.conv_math!r}")
@@ -91,15 +99,17 @@ class M3AEEncoder:
         self.grad = torch.zeros(off, **f32)
         self.p = {k: self.flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
         self.g = {k: self.grad[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
-        # ---- parameters of the other modality's input path: never used, never receive a gradient (kept for state_dict)
+        # ---- parameters of the other modality's input path: never used, never receive a gradient (grad stays None, so
+        # SGD skips them, like the reference); registered below with their own storage, reference shapes
         if kind == "text":
-            self.unused = {"image_embedding.weight": torch.zeros((patch_dim, D), **f32), "image_embedding.bias": torch.zeros(D, **f32),
-                           "encoder_image_type_embedding": torch.zeros(D, **f32)}
+            unused_shapes = {"image_embedding.weight": (D, patch_dim), "image_embedding.bias": (D,),
+                             "encoder_image_type_embedding": (1, 1, D)}
         elif kind == "image":
-            self.unused = {"text_embedding.weight": torch.zeros((text_vocab_size, D), **f32),
-                           "encoder_text_type_embedding": torch.zeros(D, **f32)}
+            unused_shapes = {"text_embedding.weight": (text_vocab_size, D), "encoder_text_type_embedding": (1, 1, D)}
         else:
-            self.unused = {}     # CAVMAEFT's visual branch / unused norms are not materialised (never touched by forward_feat(.,'a'))
+            unused_shapes = {}   # CAVMAEFT's visual branch / unused norms are not materialised (never touched by forward_feat(.,'a'))
+        self.unused: Dict[str, nn.Parameter] = {}
+        self._register_reference_tree(unused_shapes)
         self._pos: Dict[int, torch.Tensor] = {}
         self._ws: dict = {}
         self._key = None
@@ -138,14 +148,49 @@ class M3AEEncoder:
         return None if e is None else e[which]
 
     def train(self, mode: bool = True):
-        self.training = bool(mode)
+        super().train(mode)
         self._wsplit_dirty = True
         return self
 
-    def eval(self):
-        return self.train(False)
+    # ---- reference-named parameter tree -----------------------------------------------------------
+    def _to_ref(self, name: str):
+        """internal flat view -> reference-shaped VIEW (no copy)."""
+        D = self.D
+        if name == "patch_embed_a.proj.weight":
+            return lambda t: t.t().view(D, 1, 16, 16)                                    # Conv2d(1, D, 16, 16) weight (cav_mae.py:80)
+        if name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding", "modality_a"):
+            return lambda t: t.view(1, 1, -1)
+        if name == "pos_embed_a":
+            return lambda t: t.view(1, *t.shape)
+        if len(self.layout[name][1]) == 2 and name != "text_embedding.weight":
+            return lambda t: t.t()                                                       # nn.Linear.weight is (out, in)
+        return lambda t: t
+
+    def _register_reference_tree(self, unused_shapes: Dict[str, Tuple[int, ...]]) -> None:
+        if self.kind == "audio":
+            order = ["modality_a", "pos_embed_a", "patch_embed_a.proj.weight", "patch_embed_a.proj.bias"]
+        else:
+            order = ["encoder_image_type_embedding", "encoder_text_type_embedding", "cls_token", "text_embedding.weight",
+                     "image_embedding.weight", "image_embedding.bias"]
+        order += [k for k in self.layout if k.startswith("encoder.")]
+        for name in order:
+            if name in self.layout:
+                p = self._param_view(self.p[name], self.g[name], self._to_ref(name), self._ref_name(name))
+            else:
+                p = nn.Parameter(torch.zeros(unused_shapes[name], device=self.device, dtype=torch.float32))
+                p._mla_owner = self
+                self.unused[name] = p
+            parent, leaf = self._descend(self, self._ref_name(name))
+            parent.register_parameter(leaf, p)
+        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._await_tail())
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        self._await_tail()
+        self._wsplit_dirty = True
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
     def reset_parameters(self, seed: Optional[int] = None) -> None:
         """Module-default initialisation of the reference (m3ae.py:306-324; nn.Linear / nn.LayerNorm defaults)."""
         gen = torch.Generator(device="cpu")
@@ -194,61 +239,6 @@ class M3AEEncoder:
             if rest.startswith(k + "."):
                 return pre + v + rest[len(k):]
         raise KeyError(name)
-
-    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
-        """Reference keys and layouts (nn.Linear.weight is (out, in); type embeddings / cls are (1,1,D))."""
-        self._await_tail()
-        sd = {}
-        for name in self.layout:
-            t = self.p[name]
-            if self.kind == "audio":
-                key = prefix + self._ref_name(name)
-                if name == "patch_embed_a.proj.weight":
-                    sd[key] = t.t().contiguous().view(self.D, 1, 16, 16)                   # Conv2d(1, D, 16, 16) weight
-                elif name == "modality_a":
-                    sd[key] = t.clone().view(1, 1, -1)
-                elif name == "pos_embed_a":
-                    sd[key] = t.clone().view(1, *t.shape)
-                elif t.dim() == 2:
-                    sd[key] = t.t().contiguous()
-                else:
-                    sd[key] = t.clone()
-                continue
-            if name in ("cls_token", "encoder_text_type_embedding", "encoder_image_type_embedding"):
-                sd[prefix + name] = t.clone().view(1, 1, -1)
-            elif t.dim() == 2 and name != "text_embedding.weight":
-                sd[prefix + name] = t.t().contiguous()
-            else:
-                sd[prefix + name] = t.clone()
-        for name, t in self.unused.items():
-            if name.endswith("type_embedding"):
-                sd[prefix + name] = t.clone().view(1, 1, -1)
-            elif name == "image_embedding.weight":
-                sd[prefix + name] = t.t().contiguous()
-            else:
-                sd[prefix + name] = t.clone()
-        return sd
-
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "", strict: bool = True) -> None:
-        self._await_tail()
-        self._wsplit_dirty = True
-        for name in list(self.layout) + list(self.unused):
-            key = prefix + self._ref_name(name)
-            if key not in sd:
-                if strict:
-                    raise KeyError(f"missing key {key}")
-                continue
-            src = sd[key].to(self.device, torch.float32)
-            dst = self.p[name] if name in self.layout else self.unused[name]
-            if name == "patch_embed_a.proj.weight":
-                src = src.reshape(self.D, -1).t()
-            elif name == "pos_embed_a":
-                src = src.reshape(dst.shape)
-            elif src.dim() == 3:
-                src = src.reshape(-1)
-            elif src.dim() == 2 and name != "text_embedding.weight":
-                src = src.t()
-            dst.copy_(src)
 
     def grads_as_reference(self) -> Dict[str, torch.Tensor]:
         out = {}
@@ -317,9 +307,10 @@ class M3AEEncoder:
         ws["colsum"] = torch.empty(D, **f32)
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, inp: torch.Tensor, padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, inp: torch.Tensor, padding_mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """text: inp = token ids (B,1,L) or (B,L) int64, padding_mask (B,1,L)/(B,L) float (1 = padded);
-        image: inp = (B,3,256,256) fp32.  Returns the (B, D) token-mean feature (basic_model.py:182-200)."""
+        image: inp = (B,3,256,256) fp32.  Returns the (B, D) token-mean feature (basic_model.py:182-200), written into
+        `out` if given (else into the reused workspace buffer)."""
         self._await_tail()
         st = ops.cur_stream()
         D, H = self.D, self.H
@@ -380,9 +371,10 @@ class M3AEEncoder:
         ws["xlast"] = x
         ops.layernorm_fwd(x, self.p["encoder.layer_norm.weight"], self.p["encoder.layer_norm.bias"], ws["y"], ws["stf"][0], ws["stf"][1],
                           M, D, stream=st)                                                                                            # m3ae.py:176
-        ops.avgpool_fwd(ws["y"], ws["feat"], B, n, D, stream=st)                              # .mean(dim=1) over all 1+L tokens
+        feat = ws["feat"] if out is None else out
+        ops.avgpool_fwd(ws["y"], feat, B, n, D, stream=st)                                    # .mean(dim=1) over all 1+L tokens
         self._pa = n
-        return ws["feat"]
+        return feat
 
     # ------------------------------------------------------------------------------------------
     def backward_from_pooled(self, dfeat: torch.Tensor, P: Optional[int] = None) -> None:
@@ -452,12 +444,12 @@ class M3AEEncoder:
             ops.linear_wgrad(ws["patches"], dimg, self.g["image_embedding.weight"], wgw, 1, B * L, self.PD, D, stream=st, split=self.split)
 
 
-class M3AEClassifier:
+class M3AEClassifier(_Classifier):
     """models/basic_model.py:127-200 under --gs_flag: mae_a (text) + mae_v (image) + ConcatFusion(768 -> C)."""
 
     def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None,
                  conv_math: Optional[str] = None):
-        from .model import ConcatFusion, N_CLASSES
+        super().__init__()
         fusion = getattr(args, "fusion_method", "concat")
         dataset = getattr(args, "dataset", "Food101")
         if dataset not in ("MVSA", "Food101", "CREMAD"):                            # basic_model.py:132-144
@@ -471,65 +463,44 @@ class M3AEClassifier:
         self.fusion_module = ConcatFusion(768, N_CLASSES[dataset], device, s(2))   # basic_model.py:149
         self.mae_a = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(0), conv_math=conv_math)    # :166
         self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1), conv_math=conv_math)   # :167
-        self.module = self
 
     def mla_encoders(self):
         return [("a", "text", self.mae_a), ("v", "image", self.mae_v)]
 
-    def train(self, mode: bool = True):      # LayerNorm / no dropout (att_drop = drop = drop_path = 0): mode-free
-        self.training = bool(mode)
-        for _t, _g, enc in self.mla_encoders():
-            enc.train(mode)
-        return self
-
-    def eval(self):
-        return self.train(False)
+    def forward_raw(self, token: torch.Tensor, padding_mask: torch.Tensor, visual: torch.Tensor):
+        """Kernel-level joint forward into the reused feature buffers (MLATrainer / Evaluator; no autograd)."""
+        return self.mae_a.forward(token, padding_mask), self.mae_v.forward(visual)
 
     def forward(self, token: torch.Tensor, padding_mask: torch.Tensor, visual: torch.Tensor):
-        """a, v = model(token, padding_mask, image)  (main.py:426; basic_model.py:182-200)."""
-        a = self.mae_a.forward(token, padding_mask)
-        v = self.mae_v.forward(visual)
+        """a, v = model(token, padding_mask, image)  (main.py:426; basic_model.py:182-200), with autograd history."""
+        B, D = visual.shape[0], self.mae_a.D
+        a = self._feature(self.mae_a, lambda out: self.mae_a.forward(token, padding_mask, out), B, D)
+        v = self._feature(self.mae_v, lambda out: self.mae_v.forward(visual, None, out), B, D)
         return a, v
 
     def forward_split(self, token: torch.Tensor, padding_mask: torch.Tensor, visual: torch.Tensor):
         """Per-encoder forward closures in alternation order (for the trainer's per-encoder streams)."""
         return [lambda: self.mae_a.forward(token, padding_mask), lambda: self.mae_v.forward(visual)]
 
-    __call__ = forward
 
-    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
-        sd = {}
-        sd.update(self.fusion_module.fc_out.state_dict(prefix + "fusion_module.fc_out."))
-        sd.update(self.mae_a.state_dict(prefix + "mae_a."))
-        sd.update(self.mae_v.state_dict(prefix + "mae_v."))
-        return sd
-
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
-        if any(k.startswith("module.") for k in sd):
-            sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
-        self.mae_a.load_state_dict(sd, "mae_a.", strict)
-        self.mae_v.load_state_dict(sd, "mae_v.", strict)
-        if "fusion_module.fc_out.weight" in sd:
-            self.fusion_module.fc_out.load_state_dict(sd, "fusion_module.fc_out.")
-        elif strict:
-            raise KeyError("missing key fusion_module.fc_out.weight")
-
-
-class ConcatFusion3:
+class ConcatFusion3(nn.Module):
     """models/fusion_modules.py:26-35; under --gs_flag only `fc_out` is touched (main.py:432, 444, 456)."""
 
     def __init__(self, input_dim: int = 768, output_dim: int = 4, device="cuda", seed: Optional[int] = None):
-        from .model import SharedHead
+        super().__init__()
         self.fc_out = SharedHead(input_dim, output_dim, device, seed)
 
+    def forward(self, x, y, z):
+        raise NotImplementedError("mla_hip implements the --gs_flag (MLA) path only: fc_out is applied per modality")
 
-class Modal3Classifier:
+
+class Modal3Classifier(_Classifier):
     """models/basic_model.py:202-275 under --gs_flag: CAV-MAE audio (mae_a) + M3AE image (mae_v) + M3AE text (mae_t),
     shared head Linear(768 -> 4); MLA alternates a -> v -> t (main.py:432-466)."""
 
     def __init__(self, args, device="cuda", depth: int = 12, text_vocab_size: int = 30522, seed: Optional[int] = None,
                  conv_math: Optional[str] = None):
-        from .model import N_CLASSES
+        super().__init__()
         fusion = getattr(args, "fusion_method", "concat")
         dataset = getattr(args, "dataset", "IEMOCAP")
         if dataset != "IEMOCAP":                                                    # basic_model.py:208-211
@@ -544,46 +515,21 @@ class Modal3Classifier:
         self.mae_a = M3AEEncoder("audio", device, depth=depth, seed=s(0), conv_math=conv_math)                                     # :231 CAVMAEFT
         self.mae_v = M3AEEncoder("image", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(1), conv_math=conv_math)   # :232
         self.mae_t = M3AEEncoder("text", device, depth=depth, text_vocab_size=text_vocab_size, seed=s(2), conv_math=conv_math)    # :233
-        self.module = self
 
     def mla_encoders(self):
         return [("a", "audio", self.mae_a), ("v", "image", self.mae_v), ("t", "text", self.mae_t)]
 
-    def train(self, mode: bool = True):
-        self.training = bool(mode)
-        for _t, _g, enc in self.mla_encoders():
-            enc.train(mode)
-        return self
-
-    def eval(self):
-        return self.train(False)
+    def forward_raw(self, token, padding_mask, visual, audio):
+        return self.mae_a.forward(audio), self.mae_v.forward(visual), self.mae_t.forward(token, padding_mask)
 
     def forward(self, token, padding_mask, visual, audio):
-        """a, v, t = model(token, padding_mask, image, spec)  (main.py:424; basic_model.py:252-275)."""
-        a = self.mae_a.forward(audio)
-        v = self.mae_v.forward(visual)
-        t = self.mae_t.forward(token, padding_mask)
+        """a, v, t = model(token, padding_mask, image, spec)  (main.py:424; basic_model.py:252-275), with autograd history."""
+        B, D = visual.shape[0], self.mae_a.D
+        a = self._feature(self.mae_a, lambda out: self.mae_a.forward(audio, None, out), B, D)
+        v = self._feature(self.mae_v, lambda out: self.mae_v.forward(visual, None, out), B, D)
+        t = self._feature(self.mae_t, lambda out: self.mae_t.forward(token, padding_mask, out), B, D)
         return a, v, t
 
     def forward_split(self, token, padding_mask, visual, audio):
         return [lambda: self.mae_a.forward(audio), lambda: self.mae_v.forward(visual),
                 lambda: self.mae_t.forward(token, padding_mask)]
-
-    __call__ = forward
-
-    def state_dict(self, prefix: str = "") -> Dict[str, torch.Tensor]:
-        sd = {}
-        sd.update(self.fusion_module.fc_out.state_dict(prefix + "fusion_module.fc_out."))
-        for nm, enc in (("mae_a.", self.mae_a), ("mae_v.", self.mae_v), ("mae_t.", self.mae_t)):
-            sd.update(enc.state_dict(prefix + nm))
-        return sd
-
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
-        if any(k.startswith("module.") for k in sd):
-            sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
-        for nm, enc in (("mae_a.", self.mae_a), ("mae_v.", self.mae_v), ("mae_t.", self.mae_t)):
-            enc.load_state_dict(sd, nm, strict)
-        if "fusion_module.fc_out.weight" in sd:
-            self.fusion_module.fc_out.load_state_dict(sd, "fusion_module.fc_out.")
-        elif strict:
-            raise KeyError("missing key fusion_module.fc_out.weight")

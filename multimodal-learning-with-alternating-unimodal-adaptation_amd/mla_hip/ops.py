@@ -321,6 +321,28 @@ def head_ce_fwd_bwd(X, W, b, labels, logits, loss, dW, db, dX, ws, inv_batch: fl
           "mla_head_ce_fwd_bwd")
 
 
+def ce_fwd_bwd(logits, labels, loss, dlogits, ws, inv_batch: float, stream: Optional[int] = None) -> None:
+    """nn.CrossEntropyLoss() forward + d logits (main.py:130, 434); ws: B floats."""
+    B, C = logits.shape
+    check(_lib.load().mla_ce_fwd_bwd(_p(logits), _p(labels, torch.int64), _p(loss), _p(dlogits), _p(ws), B, C, inv_batch,
+                                     stream or cur_stream()), "mla_ce_fwd_bwd")
+
+
+def head_bwd(X, W, dlogits, dW, db, dX, scale: float = 1.0, stream: Optional[int] = None) -> None:
+    """autograd of fc_out for a given d logits: dW, db, dX (all times `scale`)."""
+    B, D = X.shape
+    C = W.shape[0]
+    if tuple(dlogits.shape) != (B, C):
+        raise MLAHipError(f"head_bwd: dlogits {tuple(dlogits.shape)} does not match ({B}, {C})")
+    check(_lib.load().mla_head_bwd(_p(X), _p(W), _p(dlogits), _p(dW), _p(db), _p(dX), B, D, C, scale, stream or cur_stream()),
+          "mla_head_bwd")
+
+
+def scale_by_device_scalar(x, scalar, stream: Optional[int] = None) -> None:
+    check(_lib.load().mla_scale_by_device_scalar(_p(x), _p(scalar), x.numel(), stream or cur_stream()),
+          "mla_scale_by_device_scalar")
+
+
 def colsum(X, r, scale: float, stream: Optional[int] = None) -> None:
     B, D = X.shape
     check(_lib.load().mla_colsum(_p(X), _p(r), B, D, scale, stream or cur_stream()), "mla_colsum")

@@ -108,7 +108,7 @@ class MLATrainer:
             self.last[f"r_mean_{name}"] = None if r_mean is None else r_mean.clone()
         if fires:
             self.gs_plugin.before_update(self.head, feat, batch_step, len_dataloader, self.gs_plugin.exp_count,
-                                         r_mean=r_mean)                                       # :437-438
+                                         r_mean=r_mean, grad=self.head.weight_grad)           # :437-438
         if self.keep_debug:
             self.last[f"head_grad_{name}"] = self.head.weight_grad.clone()
         opt = self.optimizer
@@ -151,7 +151,7 @@ class MLATrainer:
                     ev.record()
                     fwd_done.append(ev)
         else:
-            feats = m.forward(*inputs)
+            feats = m.forward_raw(*inputs)
         for k, ((tag, grp, enc), feat) in enumerate(zip(self.encoders, feats)):
             bs = self._estreams[k] if self.overlap_forward else None
             if bs is not None:
@@ -205,7 +205,7 @@ class Evaluator:
             if spec.dim() == 3:
                 spec = spec.unsqueeze(1)
             inputs = (spec.float(), image.float())
-        feats = self.model.forward(*inputs)
+        feats = self.model.forward_raw(*inputs)
         outs = [self.head.logits(f, slot="eval_" + str(k)) for k, f in enumerate(feats)]
         ops.eval_fuse(outs, label, self.counts, self.weights, self.dynamic, self.alphas)
         return outs

@@ -92,7 +92,7 @@ def test_avclassifier_error_behaviour_cpu():
         AVClassifier(A(), device="cpu")
     A.fusion_method = "concat"
     m = AVClassifier(A(), device="cpu", seed=0)
-    sd = m.state_dict("module.")
+    sd = m.state_dict(prefix="module.")
     assert "module.audio_net.conv1.weight" in sd and "module.fusion_module.fc_out.weight" in sd
     assert sd["module.visual_net.conv1.weight"].shape == (64, 3, 7, 7)
     assert m.module.fusion_module.fc_out.weight.shape == (6, 512)
