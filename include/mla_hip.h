@@ -203,6 +203,15 @@ int mla_bgemm(const float* A, const float* B, float* C, int batches, int heads, 
 int mla_softmax_fwd(float* S, const float* pad_mask, int B, int H, int n, void* stream);
 /* dS = P * (dP - rowsum(dP*P)), in place in dP. */
 int mla_softmax_bwd(const float* P, float* dP, int B, int H, int n, void* stream);
+
+/* Fused multi-head attention (models/m3ae.py:102-125; timm Attention behind cav_mae.py:93), exact fp32 MFMA, head dim 64.
+ * qkv (B, n, 3, H, 64) as written by the fused qkv Linear; pad_mask (B, n) float or null (mask > 0: score := -1e7,
+ * m3ae.py:111-117); o (B, n, H*64); lse (B, H, n) = log-sum-exp of every score row (saved for the backward).  The n x n
+ * scores never reach HBM: online softmax forward, recomputation backward (two kernels: dQ owns query rows and also writes
+ * dvec (B, H, n) = rowsum(d_o * o); dK / dV own key rows), no atomics -> bitwise reproducible.  dqkv has qkv's layout. */
+int mla_attention_fwd(const float* qkv, const float* pad_mask, float* o, float* lse, int B, int H, int n, int hd, void* stream);
+int mla_attention_bwd(const float* d_o, const float* qkv, const float* o, const float* lse, const float* pad_mask,
+                      float* dqkv, float* dvec, int B, int H, int n, int hd, void* stream);
 /* forward_representation token assembly (m3ae.py:342-366): x0[b][0] = cls; x0[b][1+i] = (table[ids[b][i]] if
  * table else x0[b][1+i]) + pos[i] + type.  x0 is (B, L+1, D).  cls == NULL (CAV-MAE, cav_mae.py:341-343): no
  * [cls] row, x0 is (B, L, D) and x0[b][i] += pos[i] + type. */

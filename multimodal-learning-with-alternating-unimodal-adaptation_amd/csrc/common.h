@@ -48,6 +48,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Logical tile id -> (tm, tn).  Narrow outputs (gridN <= 8: every ResNet conv) keep the row-major order.  Wide outputs
+// (transformer Linears: N = 768..3072, up to 48 column tiles) are walked in column PANELS of 8 tiles: all row tiles of a
+// panel before the next panel, so the panel's B operand (8 x BN x K x 4 B <= 3 MB) stays in the 4 MB per-XCD L2 while A
+// streams through once per panel.  Row-major order re-read the whole weight matrix (7-9 MB) from the fabric for every row
+// of tiles: 1.8 GB per 16448 x 2304 x 768 GEMM, which held the Linear layers at 76 TFLOP/s (profiles/r02_m3ae_*).
+__device__ __forceinline__ void tile_coords(int wg, int gridM, int gridN, int& tm, int& tn) {
+  if (gridN <= 8) {
+    tm = wg / gridN;
+    tn = wg - tm * gridN;
+    return;
+  }
+  const int per_panel = gridM * 8;
+  int panel = wg / per_panel;
+  const int full = gridN >> 3;                     // panels of width 8; a narrower one follows if gridN % 8 != 0
+  if (panel > full) panel = full;
+  const int rem = wg - panel * per_panel;
+  const int pw = panel < full ? 8 : gridN - full * 8;
+  tm = rem / pw;
+  tn = panel * 8 + (rem - tm * pw);
+}
+
 // Bijective XCD-aware remap of a flat workgroup id: consecutive logical ids land on the same XCD
 // (blocks b and b+8 share an XCD/L2 under round-robin dispatch).  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

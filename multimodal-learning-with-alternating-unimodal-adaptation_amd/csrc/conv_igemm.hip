@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const float* __restrict__
   const int wm = wave / WN, wn = wave % WN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int gridN = g.CO / BN;
-  const int tm = wg / gridN, tn = wg % gridN;
+  int tm, tn;
+  tile_coords(wg, (int)gridDim.x / gridN, gridN, tm, tn);
   const int gH = g.H, gW = g.W, gC = g.C, gCO = g.CO;
 
   for (int r = tid; r < BM; r += 256) {

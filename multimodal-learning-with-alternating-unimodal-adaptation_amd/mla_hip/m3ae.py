@@ -67,6 +67,12 @@ class M3AEEncoder(FlatModule):
         if self.conv_math not in ("f32", "split"):
             raise MLAHipError(f"conv_math must be 'f32' or 'split', got {self.conv_math!r}")
         self.split = self.conv_math == "split"
+        # "fused": one flash-style kernel per direction, scores never materialised (csrc/attention.hip); "materialized": the
+        # round-1 form (QK^T -> masked softmax -> PV as strided batched GEMMs, probabilities kept in HBM), kept as a
+        # cross-check of the fused kernels at full size and for A/B measurements
+        self.attention = os.environ.get("MLA_ATTENTION", "fused")
+        if self.attention not in ("fused", "materialized"):
+            raise MLAHipError(f"MLA_ATTENTION must be 'fused' or 'materialized', got {self.attention!r}")
         self.kind, self.device = kind, torch.device(device)
         if kind == "audio":
             patch_dim = 256                  # conv 16x16 over 1 channel (cav_mae.py:127)
@@ -287,6 +293,10 @@ class M3AEEncoder(FlatModule):
             ws["patches"] = torch.empty((B * L, self.PD), **f32)
         if self.kind != "audio":
             ws["pos"] = sincos_pos_embed(D, L, two_d=(self.kind == "image")).to(self.device)
+        if self.attention == "fused":
+            for bk in ws["blocks"]:
+                del bk["P"]
+                bk["lse"] = torch.empty((B, H, n), **f32)
         self._ws, self._key = ws, (B, L)
         return ws
 
@@ -298,7 +308,10 @@ class M3AEEncoder(FlatModule):
         ws["dA"], ws["dB"], ws["dC"] = (torch.empty((M, D), **f32) for _ in range(3))
         ws["du"] = torch.empty((M, 4 * D), **f32)
         ws["dqkv"] = torch.empty((M, 3 * D), **f32)
-        ws["dP"] = torch.empty((B, H, n, n), **f32)
+        if self.attention == "fused":
+            ws["dvec"] = torch.empty((B, H, n), **f32)
+        else:
+            ws["dP"] = torch.empty((B, H, n, n), **f32)
         ws["wt_ws"] = torch.empty(4 * D * D, **f32)
         wb = max(ops.linear_wgrad_ws_bytes(m_, k_, n_, sp) for sp in ((False, True) if self.split else (False,))
                  for (m_, k_, n_) in ((M, D, 3 * D), (M, D, 4 * D), (M, 4 * D, D), (M, D, D), (B * ws["L"], self.PD, D)))
@@ -357,10 +370,13 @@ class M3AEEncoder(FlatModule):
             bk["x"] = x
             ops.layernorm_fwd(x, P_("layer_norm1.weight"), P_("layer_norm1.bias"), bk["h1"], bk["st"][0], bk["st"][1], M, D, stream=st)
             ops.linear_fwd(bk["h1"], P_("attention.qkv_linear.weight"), P_("attention.qkv_linear.bias"), bk["qkv"], 1, M, D, 3 * D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.qkv_linear.weight", 0))
-            qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
-            ops.bgemm(bk["qkv"], bk["qkv"], bk["P"], B, H, n, n, hd, qs, (n * 3 * D, hd, 1, 3 * D), ss, scale, b_off=D, stream=st)   # m3ae.py:109
-            ops.softmax_fwd(bk["P"], ws["pm"], B, H, n, stream=st)                                                                    # :111-118
-            ops.bgemm(bk["P"], bk["qkv"], bk["o"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), os_, 1.0, b_off=2 * D, stream=st)   # :121-122
+            if self.attention == "fused":
+                ops.attention_fwd(bk["qkv"], ws["pm"], bk["o"], bk["lse"], B, H, n, hd, stream=st)                                   # m3ae.py:109-122
+            else:
+                qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
+                ops.bgemm(bk["qkv"], bk["qkv"], bk["P"], B, H, n, n, hd, qs, (n * 3 * D, hd, 1, 3 * D), ss, scale, b_off=D, stream=st)   # m3ae.py:109
+                ops.softmax_fwd(bk["P"], ws["pm"], B, H, n, stream=st)                                                                    # :111-118
+                ops.bgemm(bk["P"], bk["qkv"], bk["o"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), os_, 1.0, b_off=2 * D, stream=st)   # :121-122
             ops.linear_fwd(bk["o"], P_("attention.fc.weight"), P_("attention.fc.bias"), bk["xmid"], 1, M, D, D, residual=x, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.fc.weight", 0))  # :123,149
             ops.layernorm_fwd(bk["xmid"], P_("layer_norm2.weight"), P_("layer_norm2.bias"), bk["h2"], bk["st"][2], bk["st"][3], M, D, stream=st)
             ops.linear_fwd(bk["h2"], P_("transformer_mlp.fc1.weight"), P_("transformer_mlp.fc1.bias"), bk["u"], 1, M, D, 4 * D,
@@ -407,13 +423,16 @@ class M3AEEncoder(FlatModule):
             ops.colsum_rows(dB_, G_("attention.fc.bias"), red, M, D, stream=st)
             ops.linear_wgrad(bk["o"], dB_, G_("attention.fc.weight"), wgw, 1, M, D, D, stream=st, split=self.split)
             ops.linear_dgrad(dB_, P_("attention.fc.weight"), dC, wtw, 1, M, D, D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.fc.weight", 1))                    # d o (B,n,D)
-            qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
-            ops.bgemm(dC, bk["qkv"], ws["dP"], B, H, n, n, hd, os_, (n * 3 * D, hd, 1, 3 * D), ss, 1.0, b_off=2 * D, stream=st)          # dP = dO V^T
-            ops.bgemm(bk["P"], dC, ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * D, hd, D, 1), qs, 1.0, c_off=2 * D, stream=st)   # dV = P^T dO
-            ops.softmax_bwd(bk["P"], ws["dP"], B, H, n, stream=st)                                                                       # dS
-            ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), qs, scale, b_off=D, stream=st)     # dQ = s dS K
-            ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * 3 * D, hd, 3 * D, 1), qs, scale,
-                      c_off=D, stream=st)                                                                                                # dK = s dS^T Q
+            if self.attention == "fused":
+                ops.attention_bwd(dC, bk["qkv"], bk["o"], bk["lse"], ws["pm"], ws["dqkv"], ws["dvec"], B, H, n, hd, stream=st)
+            else:
+                qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
+                ops.bgemm(dC, bk["qkv"], ws["dP"], B, H, n, n, hd, os_, (n * 3 * D, hd, 1, 3 * D), ss, 1.0, b_off=2 * D, stream=st)          # dP = dO V^T
+                ops.bgemm(bk["P"], dC, ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * D, hd, D, 1), qs, 1.0, c_off=2 * D, stream=st)   # dV = P^T dO
+                ops.softmax_bwd(bk["P"], ws["dP"], B, H, n, stream=st)                                                                       # dS
+                ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), qs, scale, b_off=D, stream=st)     # dQ = s dS K
+                ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * 3 * D, hd, 3 * D, 1), qs, scale,
+                          c_off=D, stream=st)                                                                                                # dK = s dS^T Q
             ops.colsum_rows(ws["dqkv"], G_("attention.qkv_linear.bias"), red, M, 3 * D, stream=st)
             ops.linear_wgrad(bk["h1"], ws["dqkv"], G_("attention.qkv_linear.weight"), wgw, 1, M, D, 3 * D, stream=st, split=self.split)
             ops.linear_dgrad(ws["dqkv"], P_("attention.qkv_linear.weight"), dC, wtw, 1, M, D, 3 * D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.qkv_linear.weight", 1))  # d h1

@@ -446,6 +446,17 @@ def softmax_bwd(P, dP, B: int, H: int, n: int, stream: Optional[int] = None):
     check(_lib.load().mla_softmax_bwd(_p(P), _p(dP), B, H, n, stream or cur_stream()), "mla_softmax_bwd")
 
 
+def attention_fwd(qkv, pad_mask, o, lse, B: int, H: int, n: int, hd: int, stream: Optional[int] = None):
+    """o = softmax(mask(q k^T * hd^-0.5)) v, fused (models/m3ae.py:102-125); lse (B, H, n) is kept for the backward."""
+    check(_lib.load().mla_attention_fwd(_p(qkv), _p(pad_mask), _p(o), _p(lse), B, H, n, hd, stream or cur_stream()),
+          "mla_attention_fwd")
+
+
+def attention_bwd(do, qkv, o, lse, pad_mask, dqkv, dvec, B: int, H: int, n: int, hd: int, stream: Optional[int] = None):
+    check(_lib.load().mla_attention_bwd(_p(do), _p(qkv), _p(o), _p(lse), _p(pad_mask), _p(dqkv), _p(dvec), B, H, n, hd,
+                                        stream or cur_stream()), "mla_attention_bwd")
+
+
 def tokens_assemble(x0, table, ids, pos, type_emb, cls, B: int, L: int, D: int, stream: Optional[int] = None):
     check(_lib.load().mla_tokens_assemble(_p(x0), _p(table), _p(ids, torch.int64), _p(pos), _p(type_emb), _p(cls), B, L, D,
                                           stream or cur_stream()), "mla_tokens_assemble")

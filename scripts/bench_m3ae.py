@@ -10,6 +10,10 @@ B = int(os.environ.get("B", "64")); steps = int(os.environ.get("STEPS", "5")); d
 class Args: fusion_method, dataset, gs_flag, modulation = "concat", "Food101", True, "Normal"
 model = M3AEClassifier(Args(), depth=depth, seed=1, conv_math=os.environ.get("MATH", "f32"))
 tr = MLATrainer(model)
+if os.environ.get("F32_CFG"):
+    ops.conv2d_f32_cfg(int(os.environ["F32_CFG"]))      # measurement hook: force one fp32 tile (0: 128x128, 1: 256x64, 2: 64x64, 3: 128x64)
+if os.environ.get("OVERLAP") == "0":
+    tr.set_overlap(False)
 g = torch.Generator(device="cuda").manual_seed(0)
 token = torch.randint(0, 30522, (B, 1, 256), device="cuda", generator=g)
 lens = torch.randint(8, 257, (B,), device="cuda", generator=g)

@@ -130,6 +130,73 @@ def test_attention_pieces(ops, B, H, n, hd):
     assert_close(dqkv.view(B, n, 3 * D), qkv.grad, atol=1e-7, rtol=3e-5, name="d qkv")
 
 
+@pytest.mark.parametrize("B,H,n,masked", [(2, 12, 257, True), (3, 4, 50, True), (1, 2, 130, False), (2, 3, 512, False), (1, 1, 1, False),
+                                           (2, 2, 33, True), (1, 12, 128, True)])
+def test_fused_attention_vs_autograd(ops, B, H, n, masked):
+    """csrc/attention.hip (online-softmax forward, recomputation backward, scores never in HBM) vs torch autograd of
+    Attention.forward (m3ae.py:102-125) on the CPU: M3AE (257 = cls + 256, padded text), CAV-MAE (512, no mask), ragged
+    and degenerate lengths (1 token; 33 = one full key tile + 1; lengths below one workgroup)."""
+    hd = 64
+    D = H * hd
+    qkv = O.portable_normal(n + B, (B, n, 3 * D), stream=1, std=0.7).requires_grad_(True)
+    pm = torch.zeros(B, n)
+    if masked:
+        for b in range(B):
+            pm[b, max(1, n - 7 * (b + 1)):] = 1.0          # position 0 ([cls]) is never padded (m3ae.py:347)
+    dO = O.portable_normal(n, (B, n, D), stream=2)
+    q4 = qkv.view(B, n, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = torch.matmul(q4[0], q4[1].transpose(-2, -1)) * hd ** -0.5
+    att = torch.where(pm[:, None, None, :].expand(att.shape) > 0, torch.tensor(-1e7), att)
+    o_ref = torch.matmul(F.softmax(att, dim=-1), q4[2]).permute(0, 2, 1, 3).reshape(B, n, D)
+    o_ref.backward(dO)
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    qd, pmd = qkv.detach().cuda(), (pm.cuda() if masked else None)
+    o, lse = f(B, n, D), f(B, H, n)
+    ops.attention_fwd(qd, pmd, o, lse, B, H, n, hd)
+    assert_close(o, o_ref.detach(), atol=1e-6, rtol=2e-5, name="attention output")
+    assert_close(lse, torch.logsumexp(att.detach(), dim=-1), atol=1e-5, rtol=1e-6, name="log-sum-exp")
+    dqkv, dvec = f(B, n, 3 * D), f(B, H, n)
+    ops.attention_bwd(dO.cuda(), qd, o, lse, pmd, dqkv, dvec, B, H, n, hd)
+    assert_close(dqkv, qkv.grad, atol=1e-6, rtol=3e-5, name="d qkv")
+    # deterministic: a second run is bit-identical (no atomics)
+    o2, lse2, dqkv2 = f(B, n, D), f(B, H, n), f(B, n, 3 * D)
+    ops.attention_fwd(qd, pmd, o2, lse2, B, H, n, hd)
+    ops.attention_bwd(dO.cuda(), qd, o2, lse2, pmd, dqkv2, dvec, B, H, n, hd)
+    assert torch.equal(o, o2) and torch.equal(dqkv, dqkv2)
+
+
+def test_fused_attention_full_size_vs_materialized(ops):
+    """BASELINE configs[3] size (B=64, 12 heads, 257 tokens, padded text): the fused kernels against the round-1
+    materialised path (strided batched GEMMs + masked softmax, itself pinned to autograd in test_attention_pieces)."""
+    B, H, n, hd = 64, 12, 257, 64
+    D = H * hd
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = torch.randn((B, n, 3 * D), device="cuda", generator=g) * 0.8
+    dO = torch.randn((B, n, D), device="cuda", generator=g)
+    lens = torch.randint(8, 257, (B,), device="cuda", generator=g)
+    pm = torch.cat([torch.zeros((B, 1), device="cuda"), (torch.arange(256, device="cuda")[None, :] >= lens[:, None]).float()], 1).contiguous()
+    f = lambda *s: torch.empty(s, device="cuda")
+    qd = qkv.view(B * n, 3 * D)
+    P, o_m = f(B, H, n, n), f(B * n, D)
+    qs, ss, os_ = (n * 3 * D, hd, 3 * D, 1), (H * n * n, n * n, n, 1), (n * D, hd, D, 1)
+    ops.bgemm(qd, qd, P, B, H, n, n, hd, qs, (n * 3 * D, hd, 1, 3 * D), ss, hd ** -0.5, b_off=D)
+    ops.softmax_fwd(P, pm, B, H, n)
+    ops.bgemm(P, qd, o_m, B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), os_, 1.0, b_off=2 * D)
+    dP, dq_m = f(B, H, n, n), torch.zeros((B * n, 3 * D), device="cuda")
+    dOd = dO.view(B * n, D)
+    ops.bgemm(dOd, qd, dP, B, H, n, n, hd, os_, (n * 3 * D, hd, 1, 3 * D), ss, 1.0, b_off=2 * D)
+    ops.bgemm(P, dOd, dq_m, B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * D, hd, D, 1), qs, 1.0, c_off=2 * D)
+    ops.softmax_bwd(P, dP, B, H, n)
+    ops.bgemm(dP, qd, dq_m, B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), qs, hd ** -0.5, b_off=D)
+    ops.bgemm(dP, qd, dq_m, B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * 3 * D, hd, 3 * D, 1), qs, hd ** -0.5, c_off=D)
+    o, lse, dqkv, dvec = f(B, n, D), f(B, H, n), f(B, n, 3 * D), f(B, H, n)
+    ops.attention_fwd(qkv, pm, o, lse, B, H, n, hd)
+    ops.attention_bwd(dO, qkv, o, lse, pm, dqkv, dvec, B, H, n, hd)
+    assert_close(o.view(B * n, D), o_m, atol=2e-6, rtol=2e-5, name="o fused vs materialised")
+    assert_close(dqkv.view(B * n, 3 * D), dq_m, atol=2e-6, rtol=5e-5, name="dqkv fused vs materialised")
+    assert torch.isfinite(lse).all()
+
+
 def test_assemble_patchify_avgpool(ops):
     B, L, D, V = 3, 256, 768, 500
     table = O.portable_normal(1, (V, D), stream=1)
