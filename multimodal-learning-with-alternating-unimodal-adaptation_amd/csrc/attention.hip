@@ -24,9 +24,13 @@
 
 #define ATT_HD 64          // head dim (ViT-B: 768 / 12)
 #define ATT_LD 68          // padded LDS row (floats): 17 x 16 B -> conflict-free ds_read_b128 across 32 rows
-#define ATT_WG_ROWS 128    // rows of the owned operand per workgroup (4 waves x 32)
 
 namespace {
+
+// exp via v_exp_f32 (2^x): the accurate expf expands to ~20 VALU instructions, 16 of them per lane and key tile were a
+// quarter of the forward's issue slots.  Relative error <= |x| 2^-23 (the rounding of x * log2 e), i.e. < 3e-6 for the
+// score range a softmax row can hold before the result underflows anyway; arguments of -inf / -1e7 give exactly 0.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 __device__ __forceinline__ int acc_row(int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; }
 
@@ -43,19 +47,27 @@ __device__ __forceinline__ size_t qkv_off(const AttGeom& g, int b, int t, int wh
 }
 
 // One 32 x 64 tile (rows t0.., zero-filled beyond n) from global into registers / from registers into padded LDS.
-// 256 threads: thread -> (row = tid / 16 + 16 p, float4 column tid % 16), p = 0, 1.
-__device__ __forceinline__ void tile_load(f32x4 (&r)[2], const float* base, size_t row_stride, int t0, int n, int tid) {
+// NT threads: float4 slot idx = tid + NT p of the 512 (row = idx / 16, float4 column idx % 16).
+template <int NT>
+struct TileRegs {
+  static constexpr int P = (512 + NT - 1) / NT;
+  f32x4 r[P];
+  __device__ __forceinline__ void load(const float* base, size_t row_stride, int t0, int n, int tid) {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int row = (tid >> 4) + 16 * p;
-    r[p] = (t0 + row < n) ? *reinterpret_cast<const f32x4*>(base + (size_t)(t0 + row) * row_stride + (tid & 15) * 4)
-                          : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < P; ++p) {
+      const int idx = tid + NT * p, row = idx >> 4;
+      r[p] = (idx < 512 && t0 + row < n) ? *reinterpret_cast<const f32x4*>(base + (size_t)(t0 + row) * row_stride + (idx & 15) * 4)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
-}
-__device__ __forceinline__ void tile_store(float* lds, const f32x4 (&r)[2], int tid) {
+  __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&lds[((tid >> 4) + 16 * p) * ATT_LD + (tid & 15) * 4]) = r[p];
-}
+    for (int p = 0; p < P; ++p) {
+      const int idx = tid + NT * p;
+      if (idx < 512) *reinterpret_cast<f32x4*>(&lds[(idx >> 4) * ATT_LD + (idx & 15) * 4]) = r[p];
+    }
+  }
+};
 
 // 32 registers of the B operand of a wave-owned row block: lane (row = lane % 32, half) holds X[row][half * 32 + kk]
 __device__ __forceinline__ void own_rows_load(float (&x)[32], const float* base, size_t row_stride, int row, int n, int half) {
@@ -122,15 +134,16 @@ __device__ __forceinline__ float key_state(const AttGeom& g, int b, int key) {
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: workgroup = 128 queries of one (b, h); loop over key tiles of 32.  o (B, n, H*64), lse (B, H, n).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, float* __restrict__ O, float* __restrict__ LSE) {
+template <int W>
+__global__ __launch_bounds__(64 * W, 2) void attn_fwd_kernel(const AttGeom g, float* __restrict__ O, float* __restrict__ LSE) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 32 * ATT_LD + 2 * 32];
   float* Ks = smem;                       // [2][32][ATT_LD]
   float* Vs = smem + 2 * 32 * ATT_LD;     // [2][32][ATT_LD]
   float* Kst = smem + 4 * 32 * ATT_LD;    // [2][32] key states
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int bh = blockIdx.y, b = bh / g.H, h = bh - b * g.H;
-  const int q = blockIdx.x * ATT_WG_ROWS + wave * 32 + (lane & 31);
-  const bool wave_active = blockIdx.x * ATT_WG_ROWS + wave * 32 < g.n;
+  const int q = blockIdx.x * (32 * W) + wave * 32 + (lane & 31);
+  const bool wave_active = blockIdx.x * (32 * W) + wave * 32 < g.n;
   const size_t rs = (size_t)3 * g.H * ATT_HD;                  // token stride inside qkv
   const float* Qb = g.qkv + qkv_off(g, b, 0, 0, h);
   const float* Kb = g.qkv + qkv_off(g, b, 0, 1, h);
@@ -144,19 +157,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, float* _
   float m_i = -INFINITY, l_i = 0.f;
 
   const int ntiles = (g.n + 31) / 32;
-  f32x4 kr[2], vr[2];
-  tile_load(kr, Kb, rs, 0, g.n, tid);
-  tile_load(vr, Vb, rs, 0, g.n, tid);
-  tile_store(Ks, kr, tid);
-  tile_store(Vs, vr, tid);
+  TileRegs<64 * W> kr, vr;
+  kr.load(Kb, rs, 0, g.n, tid);
+  vr.load(Vb, rs, 0, g.n, tid);
+  kr.store(Ks, tid);
+  vr.store(Vs, tid);
   if (tid < 32) Kst[tid] = key_state(g, b, tid);
   __syncthreads();
   for (int jt = 0; jt < ntiles; ++jt) {
     const int cur = jt & 1, nxt = cur ^ 1;
     const bool more = jt + 1 < ntiles;
     if (more) {
-      tile_load(kr, Kb, rs, (jt + 1) * 32, g.n, tid);
-      tile_load(vr, Vb, rs, (jt + 1) * 32, g.n, tid);
+      kr.load(Kb, rs, (jt + 1) * 32, g.n, tid);
+      vr.load(Vb, rs, (jt + 1) * 32, g.n, tid);
     }
     if (wave_active) {
       const float* kt = Ks + cur * 32 * ATT_LD;
@@ -175,11 +188,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, float* _
       }
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float m_new = fmaxf(m_i, mt);
-      const float alpha = expf(m_i - m_new);                     // first tile: exp(-inf) = 0
+      const float alpha = fast_exp(m_i - m_new);                     // first tile: exp(-inf) = 0
       float lt = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        p[e] = expf(p[e] - m_new);
+        p[e] = fast_exp(p[e] - m_new);
         lt += p[e];
       }
       lt += __shfl_xor(lt, 32, 64);
@@ -193,8 +206,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, float* _
       mma_tileT_acc(o0, o1, vt, p, lane);                       // O^T += V^T P^T
     }
     if (more) {
-      tile_store(Ks + nxt * 32 * ATT_LD, kr, tid);
-      tile_store(Vs + nxt * 32 * ATT_LD, vr, tid);
+      kr.store(Ks + nxt * 32 * ATT_LD, tid);
+      vr.store(Vs + nxt * 32 * ATT_LD, tid);
       if (tid < 32) Kst[nxt * 32 + tid] = key_state(g, b, (jt + 1) * 32 + tid);
     }
     __syncthreads();
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, float* _
   // all waves have passed the last barrier: the K/V buffers are free, reuse them as per-wave staging
   float* stage = smem + wave * 32 * ATT_LD;
   store_ownT(stage, o0, o1, O + (size_t)b * g.n * (g.H * ATT_HD) + (size_t)h * ATT_HD, (size_t)g.H * ATT_HD,
-             blockIdx.x * ATT_WG_ROWS + wave * 32, g.n, lane, 1.0f / l_i);
+             blockIdx.x * (32 * W) + wave * 32, g.n, lane, 1.0f / l_i);
   if (half == 0 && q < g.n) LSE[(size_t)bh * g.n + q] = m_i + logf(l_i);
 }
 
@@ -211,7 +224,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, float* _
 // backward, query side: workgroup = 128 queries; loop over key tiles.  Recomputes P^T from LSE, writes dQ and
 // Dvec[b, h, q] = sum_d dO * O (consumed by the key-side kernel).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const float* __restrict__ dO, const float* __restrict__ O,
+template <int W>
+__global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g, const float* __restrict__ dO, const float* __restrict__ O,
                                                            const float* __restrict__ LSE, float* __restrict__ Dvec,
                                                            float* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 32 * ATT_LD + 2 * 32];
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
   float* Kst = smem + 4 * 32 * ATT_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int bh = blockIdx.y, b = bh / g.H, h = bh - b * g.H;
-  const int q0 = blockIdx.x * ATT_WG_ROWS + wave * 32, q = q0 + (lane & 31);
+  const int q0 = blockIdx.x * (32 * W) + wave * 32, q = q0 + (lane & 31);
   const bool wave_active = q0 < g.n;
   const size_t rs = (size_t)3 * g.H * ATT_HD, os = (size_t)g.H * ATT_HD;
   const float* Qb = g.qkv + qkv_off(g, b, 0, 0, h);
@@ -247,19 +261,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
   for (int e = 0; e < 16; ++e) dq0[e] = dq1[e] = 0.f;
 
   const int ntiles = (g.n + 31) / 32;
-  f32x4 kr[2], vr[2];
-  tile_load(kr, Kb, rs, 0, g.n, tid);
-  tile_load(vr, Vb, rs, 0, g.n, tid);
-  tile_store(Ks, kr, tid);
-  tile_store(Vs, vr, tid);
+  TileRegs<64 * W> kr, vr;
+  kr.load(Kb, rs, 0, g.n, tid);
+  vr.load(Vb, rs, 0, g.n, tid);
+  kr.store(Ks, tid);
+  vr.store(Vs, tid);
   if (tid < 32) Kst[tid] = key_state(g, b, tid);
   __syncthreads();
   for (int jt = 0; jt < ntiles; ++jt) {
     const int cur = jt & 1, nxt = cur ^ 1;
     const bool more = jt + 1 < ntiles;
     if (more) {
-      tile_load(kr, Kb, rs, (jt + 1) * 32, g.n, tid);
-      tile_load(vr, Vb, rs, (jt + 1) * 32, g.n, tid);
+      kr.load(Kb, rs, (jt + 1) * 32, g.n, tid);
+      vr.load(Vb, rs, (jt + 1) * 32, g.n, tid);
     }
     if (wave_active) {
       const float* kt = Ks + cur * 32 * ATT_LD;
@@ -273,14 +287,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float st = Kst[cur * 32 + acc_row(e, half)];
-        const float pe = st == 0.f ? expf(s[e] * g.scale - lse) : 0.f;   // padded keys: exp(-1e7 - lse) == 0 exactly
+        const float pe = st == 0.f ? fast_exp(s[e] * g.scale - lse) : 0.f;   // padded keys: exp(-1e7 - lse) == 0 exactly
         ds[e] = pe * (dp[e] - dsum) * g.scale;
       }
       mma_tileT_acc(dq0, dq1, kt, ds, lane);                    // dQ^T += K^T dS^T
     }
     if (more) {
-      tile_store(Ks + nxt * 32 * ATT_LD, kr, tid);
-      tile_store(Vs + nxt * 32 * ATT_LD, vr, tid);
+      kr.store(Ks + nxt * 32 * ATT_LD, tid);
+      vr.store(Vs + nxt * 32 * ATT_LD, tid);
       if (tid < 32) Kst[nxt * 32 + tid] = key_state(g, b, (jt + 1) * 32 + tid);
     }
     __syncthreads();
@@ -293,7 +307,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, key side: workgroup = 128 keys; loop over query tiles of 32 (Q, dO, LSE, Dvec through LDS).  Writes dK, dV.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, const float* __restrict__ dO, const float* __restrict__ LSE,
+template <int W>
+__global__ __launch_bounds__(64 * W, 2) void attn_bwd_dkv_kernel(const AttGeom g, const float* __restrict__ dO, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dvec, float* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 32 * ATT_LD + 2 * 64];
   float* Qs = smem;
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
   float* Rs = smem + 4 * 32 * ATT_LD;      // [2][64]: lse (32) | Dvec (32) of the query tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
   const int bh = blockIdx.y, b = bh / g.H, h = bh - b * g.H;
-  const int k0 = blockIdx.x * ATT_WG_ROWS + wave * 32, key = k0 + (lane & 31);
+  const int k0 = blockIdx.x * (32 * W) + wave * 32, key = k0 + (lane & 31);
   const bool wave_active = k0 < g.n;
   const size_t rs = (size_t)3 * g.H * ATT_HD, os = (size_t)g.H * ATT_HD;
   const float* Qb = g.qkv + qkv_off(g, b, 0, 0, h);
@@ -326,19 +341,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
       Rs[buf * 64 + tid] = v;
     }
   };
-  f32x4 qr[2], dr[2];
-  tile_load(qr, Qb, rs, 0, g.n, tid);
-  tile_load(dr, dOb, os, 0, g.n, tid);
-  tile_store(Qs, qr, tid);
-  tile_store(dOs, dr, tid);
+  TileRegs<64 * W> qr, dr;
+  qr.load(Qb, rs, 0, g.n, tid);
+  dr.load(dOb, os, 0, g.n, tid);
+  qr.store(Qs, tid);
+  dr.store(dOs, tid);
   row_stats(0, 0);
   __syncthreads();
   for (int it = 0; it < ntiles; ++it) {
     const int cur = it & 1, nxt = cur ^ 1;
     const bool more = it + 1 < ntiles;
     if (more) {
-      tile_load(qr, Qb, rs, (it + 1) * 32, g.n, tid);
-      tile_load(dr, dOb, os, (it + 1) * 32, g.n, tid);
+      qr.load(Qb, rs, (it + 1) * 32, g.n, tid);
+      dr.load(dOb, os, (it + 1) * 32, g.n, tid);
     }
     if (wave_active) {
       const float* qt = Qs + cur * 32 * ATT_LD;
@@ -353,15 +368,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = acc_row(e, half);
-        p[e] = attend ? expf(s[e] * g.scale - st[r]) : 0.f;
+        p[e] = attend ? fast_exp(s[e] * g.scale - st[r]) : 0.f;
         ds[e] = p[e] * (dp[e] - st[32 + r]) * g.scale;
       }
       mma_tileT_acc(dv0, dv1, dt, p, lane);                     // dV^T += dO^T P
       mma_tileT_acc(dk0, dk1, qt, ds, lane);                    // dK^T += Q^T dS
     }
     if (more) {
-      tile_store(Qs + nxt * 32 * ATT_LD, qr, tid);
-      tile_store(dOs + nxt * 32 * ATT_LD, dr, tid);
+      qr.store(Qs + nxt * 32 * ATT_LD, tid);
+      dr.store(dOs + nxt * 32 * ATT_LD, tid);
       row_stats((it + 1) * 32, nxt);
     }
     __syncthreads();
@@ -371,6 +386,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
   store_ownT(stage, dk0, dk1, dqkv + qkv_off(g, b, 0, 1, h), rs, k0, g.n, lane, 1.0f);
   __builtin_amdgcn_wave_barrier();
   store_ownT(stage, dv0, dv1, dqkv + qkv_off(g, b, 0, 2, h), rs, k0, g.n, lane, 1.0f);
+}
+
+// Waves (= blocks of 32 owned rows) per workgroup: the sequence is cut into ceil(n / 32) wave blocks and a workgroup whose
+// last waves have no rows keeps its CU slot for the whole key loop, so pick the width that leaves the fewest idle waves
+// (n = 257 = cls + 256: nine blocks -> three workgroups of three waves instead of 4 + 4 + 1; n = 512: four).
+int att_waves(int n) {
+  const int blocks = (n + 31) / 32;
+  int best = 4, best_idle = 1 << 30;
+  for (int w = 4; w >= 2; --w) {
+    const int idle = ((blocks + w - 1) / w) * w - blocks;
+    if (idle < best_idle) { best = w; best_idle = idle; }
+  }
+  return best;
 }
 
 int check_att(const char* who, int B, int H, int n, int hd) {
@@ -387,7 +415,12 @@ extern "C" int mla_attention_fwd(const float* qkv, const float* pad_mask, float*
   MLA_REQUIRE(qkv && o && lse, "mla_attention_fwd: null pointer");
   if (int rc = check_att("mla_attention_fwd", B, H, n, hd)) return rc;
   AttGeom g{qkv, pad_mask, B, H, n, 1.0f / sqrtf((float)hd)};
-  attn_fwd_kernel<<<dim3(cdiv(n, ATT_WG_ROWS), B * H), 256, 0, (hipStream_t)stream>>>(g, o, lse);
+  const int W = att_waves(n);
+  const dim3 grid(cdiv(n, 32 * W), B * H);
+  hipStream_t st = (hipStream_t)stream;
+  if (W == 4) attn_fwd_kernel<4><<<grid, 256, 0, st>>>(g, o, lse);
+  else if (W == 3) attn_fwd_kernel<3><<<grid, 192, 0, st>>>(g, o, lse);
+  else attn_fwd_kernel<2><<<grid, 128, 0, st>>>(g, o, lse);
   MLA_CHECK_LAUNCH("attn_fwd_kernel");
   return MLA_OK;
 }
@@ -397,11 +430,16 @@ extern "C" int mla_attention_bwd(const float* d_o, const float* qkv, const float
   MLA_REQUIRE(d_o && qkv && o && lse && dqkv && dvec, "mla_attention_bwd: null pointer");
   if (int rc = check_att("mla_attention_bwd", B, H, n, hd)) return rc;
   AttGeom g{qkv, pad_mask, B, H, n, 1.0f / sqrtf((float)hd)};
-  const dim3 grid(cdiv(n, ATT_WG_ROWS), B * H);
+  const int W = att_waves(n);
+  const dim3 grid(cdiv(n, 32 * W), B * H);
   hipStream_t st = (hipStream_t)stream;
-  attn_bwd_dq_kernel<<<grid, 256, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
+  if (W == 4) attn_bwd_dq_kernel<4><<<grid, 256, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
+  else if (W == 3) attn_bwd_dq_kernel<3><<<grid, 192, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
+  else attn_bwd_dq_kernel<2><<<grid, 128, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
   MLA_CHECK_LAUNCH("attn_bwd_dq_kernel");
-  attn_bwd_dkv_kernel<<<grid, 256, 0, st>>>(g, d_o, lse, dvec, dqkv);
+  if (W == 4) attn_bwd_dkv_kernel<4><<<grid, 256, 0, st>>>(g, d_o, lse, dvec, dqkv);
+  else if (W == 3) attn_bwd_dkv_kernel<3><<<grid, 192, 0, st>>>(g, d_o, lse, dvec, dqkv);
+  else attn_bwd_dkv_kernel<2><<<grid, 128, 0, st>>>(g, d_o, lse, dvec, dqkv);
   MLA_CHECK_LAUNCH("attn_bwd_dkv_kernel");
   return MLA_OK;
 }
