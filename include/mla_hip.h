@@ -196,9 +196,12 @@ int mla_layernorm_fwd(const float* x, const float* w, const float* b, float* y, 
 int mla_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
                       const float* add, float* dx, float* dw, float* db, float* ws, int M, int D, void* stream);
 /* Strided batched GEMM for attention (m3ae.py:109, 121): C[z] = alpha * A[z] . B[z], z = (batch, head);
- * strides in elements: a = {batch, head, row i, k}, b = {batch, head, k, col j}, c = {batch, head, i, j}. */
+ * strides in elements (>= 0): a = {batch, head, row i, k}, b = {batch, head, k, col j}, c = {batch, head, i, j}.
+ * *_extent: elements addressable from each pointer; a descriptor that reaches beyond them returns MLA_ERR_INVALID_ARG
+ * (the materialised attention path; the encoders use mla_attention_* by default). */
 int mla_bgemm(const float* A, const float* B, float* C, int batches, int heads, int M, int N, int K,
-              const long* a_strides, const long* b_strides, const long* c_strides, float alpha, void* stream);
+              const long* a_strides, const long* b_strides, const long* c_strides,
+              size_t a_extent, size_t b_extent, size_t c_extent, float alpha, void* stream);
 /* In-place softmax over the last axis of S (B,H,n,n); pad_mask (B,n) float, > 0 -> score := -1e7 (m3ae.py:111-118). */
 int mla_softmax_fwd(float* S, const float* pad_mask, int B, int H, int n, void* stream);
 /* dS = P * (dP - rowsum(dP*P)), in place in dP. */
@@ -214,13 +217,14 @@ int mla_attention_bwd(const float* d_o, const float* qkv, const float* o, const 
                       float* dqkv, float* dvec, int B, int H, int n, int hd, void* stream);
 /* forward_representation token assembly (m3ae.py:342-366): x0[b][0] = cls; x0[b][1+i] = (table[ids[b][i]] if
  * table else x0[b][1+i]) + pos[i] + type.  x0 is (B, L+1, D).  cls == NULL (CAV-MAE, cav_mae.py:341-343): no
- * [cls] row, x0 is (B, L, D) and x0[b][i] += pos[i] + type. */
+ * [cls] row, x0 is (B, L, D) and x0[b][i] += pos[i] + type.  V = rows of `table`; a token id outside [0, V) makes its row
+ * NaN (nn.Embedding asserts there) and receives no gradient. */
 int mla_tokens_assemble(float* x0, const float* table, const int64_t* ids, const float* pos, const float* type,
-                        const float* cls, int B, int L, int D, void* stream);
+                        const float* cls, int B, int L, int D, int V, void* stream);
 /* its gradients: dcls, dtype (needs colsum_all = column sum of dx0 over all B*(L+1) rows) and, for text,
  * dtable[ids] += dx0 rows (float atomics; dtable pre-zeroed). */
 int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls, float* dtype,
-                            float* dtable, int B, int L, int D, void* stream);
+                            float* dtable, int B, int L, int D, int V, void* stream);
 /* einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)' (basic_model.py:184-186); also the im2col of CAV-MAE's
  * conv16x16/16 PatchEmbed (cav_mae.py:69-84).  transposed != 0: img is stored (B,C,W,H) (spectrogram (B,time,freq)
  * viewed as (B,1,freq,time), cav_mae.py:339-340). */

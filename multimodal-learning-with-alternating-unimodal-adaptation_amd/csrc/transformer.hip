@@ -252,9 +252,24 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A,
 }
 
 extern "C" int mla_bgemm(const float* A, const float* B, float* C, int batches, int heads, int M, int N, int K,
-                         const long* a_strides, const long* b_strides, const long* c_strides, float alpha, void* stream) {
+                         const long* a_strides, const long* b_strides, const long* c_strides, size_t a_extent, size_t b_extent,
+                         size_t c_extent, float alpha, void* stream) {
   MLA_REQUIRE(A && B && C && a_strides && b_strides && c_strides, "mla_bgemm: null pointer");
   MLA_REQUIRE(batches > 0 && heads > 0 && M > 0 && N > 0 && K > 0 && (long)batches * heads < 65536, "mla_bgemm: bad dims");
+  // The descriptor is all the kernel knows about the buffers: check that the largest element it can address lies inside the
+  // extent (in elements, counted from the pointer) the caller vouches for, so a wrong stride table is an error code here
+  // and not a memory fault on the device.
+  const long dims[3][4] = {{batches, heads, M, K}, {batches, heads, K, N}, {batches, heads, M, N}};
+  const long* strides[3] = {a_strides, b_strides, c_strides};
+  const size_t extents[3] = {a_extent, b_extent, c_extent};
+  for (int o = 0; o < 3; ++o) {
+    unsigned long long last = 0;
+    for (int k = 0; k < 4; ++k) {
+      MLA_REQUIRE(strides[o][k] >= 0, "mla_bgemm: negative stride (operand %d, axis %d)", o, k);
+      last += (unsigned long long)strides[o][k] * (unsigned long long)(dims[o][k] - 1);
+    }
+    MLA_REQUIRE(last < extents[o], "mla_bgemm: operand %d reaches element %llu but its extent is %zu", o, last, extents[o]);
+  }
   BGemmDesc d;
   d.M = M; d.N = N; d.K = K; d.H = heads; d.alpha = alpha;
   d.a_b = a_strides[0]; d.a_h = a_strides[1]; d.a_i = a_strides[2]; d.a_k = a_strides[3];
@@ -352,7 +367,7 @@ extern "C" int mla_softmax_bwd(const float* P, float* dP, int B, int H, int n, v
 __global__ __launch_bounds__(256) void assemble_kernel(float* __restrict__ x0, const float* __restrict__ table,
                                                         const int64_t* __restrict__ ids, const float* __restrict__ pos,
                                                         const float* __restrict__ type, const float* __restrict__ cls,
-                                                        int B, int L, int D) {
+                                                        int B, int L, int D, int V) {
   const int d4n = D >> 2;
   const int hc = cls ? 1 : 0;                       // CAV-MAE has no [cls] token (cav_mae.py:337-343)
   const size_t total = (size_t)B * (L + hc) * d4n;
@@ -365,8 +380,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(float* __restrict__ x0, c
     if (t == 0) {
       v = reinterpret_cast<const f32x4*>(cls)[c];
     } else {
-      if (table) v = reinterpret_cast<const f32x4*>(table)[(size_t)ids[b * L + t - 1] * d4n + c];
-      else v = reinterpret_cast<const f32x4*>(x0)[i];
+      if (table) {
+        const int64_t id = ids[b * L + t - 1];     // nn.Embedding asserts on an id outside [0, V): poison the row instead of
+        v = (id >= 0 && id < V) ? reinterpret_cast<const f32x4*>(table)[(size_t)id * d4n + c]      // reading out of bounds
+                                : f32x4{NAN, NAN, NAN, NAN};
+      } else {
+        v = reinterpret_cast<const f32x4*>(x0)[i];
+      }
       v += reinterpret_cast<const f32x4*>(pos)[(size_t)(t - 1) * d4n + c] + reinterpret_cast<const f32x4*>(type)[c];
     }
     reinterpret_cast<f32x4*>(x0)[i] = v;
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(float* __restrict__ x0, c
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx0, const float* __restrict__ tot,
                                                             const int64_t* __restrict__ ids, float* __restrict__ dcls,
                                                             float* __restrict__ dtype, float* __restrict__ dtable, int B,
-                                                            int L, int D) {
+                                                            int L, int D, int V) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
   if (gid < (size_t)D) {
     float s = 0.f;
@@ -395,32 +415,33 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
       const int d = (int)(i % D);
       const size_t r = i / D;
       const size_t b = r / L, t = r % L;
-      atomicAdd(&dtable[(size_t)ids[r] * D + d], dx0[(b * (L + 1) + t + 1) * D + d]);
+      const int64_t id = ids[r];
+      if (id >= 0 && id < V) atomicAdd(&dtable[(size_t)id * D + d], dx0[(b * (L + 1) + t + 1) * D + d]);   // bad ids: forward already NaN
     }
   }
 }
 
 extern "C" int mla_tokens_assemble(float* x0, const float* table, const int64_t* ids, const float* pos, const float* type,
-                                   const float* cls, int B, int L, int D, void* stream) {
-  MLA_REQUIRE(x0 && pos && type && B > 0 && L > 0 && D % 4 == 0 && ((table == nullptr) == (ids == nullptr)),
+                                   const float* cls, int B, int L, int D, int V, void* stream) {
+  MLA_REQUIRE(x0 && pos && type && B > 0 && L > 0 && D % 4 == 0 && ((table == nullptr) == (ids == nullptr)) && (!table || V > 0),
               "mla_tokens_assemble: bad argument");
   MLA_REQUIRE(cls || !table, "mla_tokens_assemble: the text path always has a [cls] token");
   size_t blocks = ((size_t)B * (L + 1) * (D / 4) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  assemble_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x0, table, ids, pos, type, cls, B, L, D);
+  assemble_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(x0, table, ids, pos, type, cls, B, L, D, V);
   MLA_CHECK_LAUNCH("assemble_kernel");
   return MLA_OK;
 }
 
 extern "C" int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls,
-                                       float* dtype, float* dtable, int B, int L, int D, void* stream) {
-  MLA_REQUIRE(dx0 && colsum_all && dtype && B > 0 && L > 0 && D > 0 && ((dtable == nullptr) == (ids == nullptr)),
+                                       float* dtype, float* dtable, int B, int L, int D, int V, void* stream) {
+  MLA_REQUIRE(dx0 && colsum_all && dtype && B > 0 && L > 0 && D > 0 && ((dtable == nullptr) == (ids == nullptr)) && (!dtable || V > 0),
               "mla_tokens_assemble_bwd: bad argument");
   MLA_REQUIRE(dcls || !dtable, "mla_tokens_assemble_bwd: the text path always has a [cls] token");
   size_t blocks = dtable ? ((size_t)B * L * D + 255) / 256 : (size_t)cdiv(D, 256);
   if (blocks > 16384) blocks = 16384;
   if (blocks < (size_t)cdiv(D, 256)) blocks = cdiv(D, 256);
-  assemble_bwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(dx0, colsum_all, ids, dcls, dtype, dtable, B, L, D);
+  assemble_bwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(dx0, colsum_all, ids, dcls, dtype, dtable, B, L, D, V);
   MLA_CHECK_LAUNCH("assemble_bwd_kernel");
   return MLA_OK;
 }

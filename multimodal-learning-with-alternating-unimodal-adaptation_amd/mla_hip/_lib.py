@@ -76,13 +76,13 @@ PROTOTYPES = {
     "mla_colsum_rows": (_I, [_P, _P, _P, _I, _I, _P]),
     "mla_layernorm_fwd": (_I, [_P] * 6 + [_I, _I, _F, _P]),
     "mla_layernorm_bwd": (_I, [_P] * 10 + [_I, _I, _P]),
-    "mla_bgemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _F, _P]),
+    "mla_bgemm": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _Z, _Z, _F, _P]),
     "mla_softmax_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mla_softmax_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "mla_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mla_attention_bwd": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
-    "mla_tokens_assemble": (_I, [_P] * 6 + [_I, _I, _I, _P]),
-    "mla_tokens_assemble_bwd": (_I, [_P] * 6 + [_I, _I, _I, _P]),
+    "mla_tokens_assemble": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
+    "mla_tokens_assemble_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
     "mla_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 

@@ -354,7 +354,11 @@ class ResNet18Encoder(FlatModule):
                 ws["x0"] = torch.empty((N, H, W, C), device=self.device, dtype=torch.float32)
             ops.video_to_nhwc(x, ws["x0"], stream=st)                      # backbone.py:144-147
         else:
-            ws["x0"] = x.view(N, H, W, 1)                                  # C == 1: NCHW == NHWC
+            # C == 1: NCHW == NHWC, but the stem weight gradient reads x0 long after forward() has returned (on the encoder's
+            # own streams), so the caller's buffer is copied: it may be a DeviceFeeder slot that is refilled meanwhile
+            if "x0" not in ws:
+                ws["x0"] = torch.empty((N, H, W, 1), device=self.device, dtype=torch.float32)
+            ws["x0"].copy_(x.view(N, H, W, 1))
         self._conv_bn(ws, st, ws["x0"], "conv1", 2, 3, ws["y_stem"], ws["a_stem"], relu=True)   # :149-151
         ops.maxpool_fwd(ws["a_stem"], ws["p0"], ws["pool_idx"], stream=st)                      # :152
         cur = ws["p0"]

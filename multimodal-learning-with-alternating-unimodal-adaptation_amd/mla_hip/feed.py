@@ -8,6 +8,14 @@ The reference does a blocking `.to(device)` per tensor at the top of every itera
 CREMA-D batch of 64 on the critical path.  `DeviceFeeder` copies each batch on a dedicated HIP stream into one of
 `depth` device slots while the previous step computes; the compute stream only waits on the copy's event, so the PCIe
 transfer (149 MB ~ 2.3-3 ms at the measured 50 GB/s) disappears behind the 37 ms step.
+
+Slot lifetime: a slot is refilled once the stream the batch was consumed on has passed the end of that step (`done`
+event).  Every encoder copies what its BACKWARD reads of the raw input (audio spectrogram for the stem weight gradient,
+token ids for the embedding scatter) into its own workspace during forward(), and the trainer's calling stream waits for
+all forwards before it returns, so no kernel touches a slot after `done` even though the encoder chains keep running on
+their own streams (tests/test_step_gpu.py::test_device_feeder_with_stream_pipeline_is_bitwise_equivalent).
+The feeder does not pin anything itself: copies are asynchronous when the loader hands over pinned tensors
+(DataLoader(pin_memory=True), main.py:785) and host-blocking (but still off the compute stream) for pageable ones.
 """
 from __future__ import annotations
 
@@ -23,7 +31,8 @@ class DeviceFeeder:
         depth >= 3: while step i runs, batch i+1 is already on the device and batch i+2 is copied into the slot of step
         i-1.  Copies are issued on a dedicated stream straight from the loader's host tensors: asynchronous for pinned
         sources (DataLoader(pin_memory=True), main.py:785), ~2.3 ms of host time per 149 MB batch for pageable ones
-        (the HIP runtime stages them at ~50 GB/s).  Slot reuse is fenced on the device by events (no host sync)."""
+        (the HIP runtime stages them at ~50 GB/s; this class pins nothing).  Slot reuse is fenced on the device by events
+        (no host sync)."""
         self.batches = batches
         self.device = torch.device(device)
         self.depth = max(3, depth)

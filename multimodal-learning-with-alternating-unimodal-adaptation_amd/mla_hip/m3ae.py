@@ -336,7 +336,10 @@ class M3AEEncoder(FlatModule):
             B, L = ids.shape
             ws = self._plan(B, L)
             pm = padding_mask.reshape(B, -1).to(torch.float32)
-            ws["ids"] = ids
+            if "ids" not in ws:
+                ws["ids"] = torch.empty_like(ids)
+            ws["ids"].copy_(ids)          # owned copy: tokens_assemble_bwd reads it after forward() returned (feeder slots are reused)
+            ids = ws["ids"]
             ws["pm"] = torch.cat([torch.zeros((B, 1), device=self.device), pm], dim=1).contiguous()   # cls is never masked (m3ae.py:347)
             ops.tokens_assemble(ws["x0"], self.p["text_embedding.weight"], ids, ws["pos"], self.p["encoder_text_type_embedding"],
                                 self.p["cls_token"], B, L, D, stream=st)

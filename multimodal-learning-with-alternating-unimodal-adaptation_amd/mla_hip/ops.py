@@ -434,8 +434,11 @@ def bgemm(A, B, C, batches: int, heads: int, M: int, N: int, K: int, a_strides, 
     L4 = ctypes.c_long * 4
     sa, sb, sc = L4(*a_strides), L4(*b_strides), L4(*c_strides)      # keep alive across the call (no temporaries!)
     pa, pb, pc = _p(A) + 4 * a_off, _p(B) + 4 * b_off, _p(C) + 4 * c_off
+    if min(a_off, b_off, c_off) < 0 or a_off >= A.numel() or b_off >= B.numel() or c_off >= C.numel():
+        raise MLAHipError("bgemm: element offset outside its buffer")
     check(_lib.load().mla_bgemm(pa, pb, pc, batches, heads, M, N, K, ctypes.addressof(sa), ctypes.addressof(sb),
-                                ctypes.addressof(sc), alpha, stream or cur_stream()), "mla_bgemm")
+                                ctypes.addressof(sc), A.numel() - a_off, B.numel() - b_off, C.numel() - c_off, alpha,
+                                stream or cur_stream()), "mla_bgemm")
 
 
 def softmax_fwd(S, pad_mask, B: int, H: int, n: int, stream: Optional[int] = None):
@@ -458,13 +461,15 @@ def attention_bwd(do, qkv, o, lse, pad_mask, dqkv, dvec, B: int, H: int, n: int,
 
 
 def tokens_assemble(x0, table, ids, pos, type_emb, cls, B: int, L: int, D: int, stream: Optional[int] = None):
-    check(_lib.load().mla_tokens_assemble(_p(x0), _p(table), _p(ids, torch.int64), _p(pos), _p(type_emb), _p(cls), B, L, D,
+    V = table.shape[0] if table is not None else 0
+    check(_lib.load().mla_tokens_assemble(_p(x0), _p(table), _p(ids, torch.int64), _p(pos), _p(type_emb), _p(cls), B, L, D, V,
                                           stream or cur_stream()), "mla_tokens_assemble")
 
 
 def tokens_assemble_bwd(dx0, colsum_all, ids, dcls, dtype, dtable, B: int, L: int, D: int, stream: Optional[int] = None):
+    V = dtable.shape[0] if dtable is not None else 0
     check(_lib.load().mla_tokens_assemble_bwd(_p(dx0), _p(colsum_all), _p(ids, torch.int64), _p(dcls), _p(dtype), _p(dtable),
-                                              B, L, D, stream or cur_stream()), "mla_tokens_assemble_bwd")
+                                              B, L, D, V, stream or cur_stream()), "mla_tokens_assemble_bwd")
 
 
 def patchify(img, out, P: int = 16, transposed_hw: Optional[tuple] = None, stream: Optional[int] = None):

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(fns) >= 26
     for name in fns:
         assert hasattr(lib, name), f"libmla_hip.so does not export {name}"
-    assert lib.mla_abi_version() == 1
+    assert lib.mla_abi_version() == 2
     assert lib.mla_last_error() is not None
 
 
@@ -113,3 +113,29 @@ def test_gs_alpha_and_sgd_state_machine_cpu():
         assert opt.grad_state["audio"] == want and opt.grad_state["visual"] == "none"     # Q6
         opt.drop_grads()
         assert set(opt.grad_state.values()) == {"none"}
+
+
+def test_bgemm_rejects_descriptors_that_leave_their_buffers():
+    """`mla_bgemm` takes raw strides; a descriptor whose largest reachable element lies outside the extent
+    the caller vouches for must come back as MLA_ERR_INVALID_ARG *before* any launch (so this runs without a GPU: the
+    pointers are never dereferenced).  The round-1 abort of test_attention_pieces[2-12-257-64] was exactly such a bad
+    descriptor: ctypes stride arrays built as temporaries and freed before the call read them."""
+    import ctypes
+    from mla_hip import _lib
+    lib = _lib.load()
+    L4 = ctypes.c_long * 4
+    B, H, n, hd = 2, 12, 257, 64
+    D = H * hd
+    qkv_elems, p_elems = B * n * 3 * D, B * H * n * n
+    fake = 0x1000                                       # non-null, never dereferenced: validation fails first
+    good_a, good_b, good_c = L4(n * 3 * D, hd, 3 * D, 1), L4(n * 3 * D, hd, 1, 3 * D), L4(H * n * n, n * n, n, 1)
+
+    def call(sa, sb, sc, ea, eb, ec):
+        return lib.mla_bgemm(fake, fake, fake, B, H, n, n, hd, ctypes.addressof(sa), ctypes.addressof(sb), ctypes.addressof(sc),
+                             ea, eb, ec, 1.0, None)
+    bad_stride = L4(n * 3 * D, hd, 3 * D * 3, 1)                        # row stride three times too large
+    assert call(bad_stride, good_b, good_c, qkv_elems, qkv_elems - D, p_elems) == -1
+    assert b"operand 0" in lib.mla_last_error()
+    assert call(good_a, good_b, good_c, qkv_elems, qkv_elems - D, p_elems - 1) == -1       # C one element short
+    assert b"operand 2" in lib.mla_last_error()
+    assert call(good_a, L4(n * 3 * D, hd, -1, 3 * D), good_c, qkv_elems, qkv_elems - D, p_elems) == -1    # negative stride

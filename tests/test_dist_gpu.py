@@ -88,3 +88,108 @@ def test_two_rank_trainer_equals_dataparallel_semantics(tmp_path, conv_math):
     for enc in ("a", "v"):
         for k, g in ref[enc]["grads"].items():
             assert_close_robust(r0["grads_" + enc][k], g, rel_l2=5e-2, elem_tol=1.0, frac=0.0, name=f"reduced grad {enc}.{k}")
+
+
+# ---- transformer trainers (configs[3] M3AE text+image, configs[4] Modal3 audio+image+text) -------------------------------
+# No BatchNorm in these encoders (LayerNorm is per token), so sharding the batch over ranks is exactly the single-process
+# global-batch step up to summation order: the 2-rank result must equal ONE process running the whole batch.
+T_DEPTH, T_VOCAB, T_B = 2, 200, 4
+
+
+def _transformer_case(which, seed=211):
+    """(model factory, state_dict, inputs tuple for train_step without label, label, n_classes)"""
+    import numpy as np
+    if which == "m3ae":
+        class A:
+            fusion_method, dataset, gs_flag, modulation = "concat", "MVSA", True, "Normal"
+        C, encs = 3, (("mae_a", O.make_m3ae_params(seed, depth=T_DEPTH, vocab=T_VOCAB)), ("mae_v", O.make_m3ae_params(seed + 1, depth=T_DEPTH, vocab=T_VOCAB)))
+    else:
+        class A:
+            fusion_method, dataset, gs_flag, modulation = "concat", "IEMOCAP", True, "Normal"
+        C, encs = 4, (("mae_a", O.make_cavmae_audio_params(seed, depth=T_DEPTH)), ("mae_v", O.make_m3ae_params(seed + 1, depth=T_DEPTH, vocab=T_VOCAB)),
+                      ("mae_t", O.make_m3ae_params(seed + 2, depth=T_DEPTH, vocab=T_VOCAB)))
+    sd = {f"{nm}.{k}": v for nm, p in encs for k, v in p.items()}
+    sd.update({f"fusion_module.fc_out.{k}": v for k, v in O.make_head_params(768, C, seed + 3).items()})
+    token = torch.from_numpy(np.minimum((O.portable_uniform(seed, T_B * 256, 7) * T_VOCAB).astype(np.int64), T_VOCAB - 1)).view(T_B, 1, 256)
+    pm = torch.zeros(T_B, 1, 256)
+    for b in range(T_B):
+        pm[b, 0, 30 + 41 * b:] = 1.0
+    image = O.portable_normal(seed, (T_B, 3, 256, 256), stream=3)
+    spec = O.portable_normal(seed, (T_B, 1024, 128), stream=4, mean=-5.081, std=4.4849)
+    label = O.portable_labels(seed, T_B, C)
+    inputs = (token, pm, image) if which == "m3ae" else (token, pm, image, spec)
+    return A, sd, inputs, label
+
+
+def _build_transformer(which, comm=None):
+    from mla_hip import M3AEClassifier, MLATrainer, Modal3Classifier
+    A, sd, inputs, label = _transformer_case(which)
+    cls = M3AEClassifier if which == "m3ae" else Modal3Classifier
+    model = cls(A(), depth=T_DEPTH, text_vocab_size=T_VOCAB, seed=0)
+    model.load_state_dict(sd)
+    tr = MLATrainer(model, gs_mode="as_intended", comm=comm)
+    tr.keep_debug = True
+    return model, tr, inputs, label
+
+
+def _collect(model, tr, losses):
+    res = {k: v.cpu().clone() for k, v in losses.items()}
+    for tag, _g, enc in model.mla_encoders():
+        res["raw_" + tag] = tr.last[f"head_grad_{tag}_raw"].cpu()
+        res["proj_" + tag] = tr.last[f"head_grad_{tag}"].cpu()
+        res["feat_" + tag] = tr.last[tag].cpu().clone()
+        res["grads_" + tag] = {k: v.cpu() for k, v in enc.grads_as_reference().items()}
+    res["Pl"], res["head"] = tr.gs_plugin.Pl.cpu(), model.fusion_module.fc_out.flat.cpu().clone()
+    return res
+
+
+def _worker_transformer(rank, port, outdir, which):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    from mla_hip import Comm
+    comm = Comm(bucket_bytes=4 << 20)
+    model, tr, inputs, label = _build_transformer(which, comm)
+    per = T_B // WORLD
+    sl = slice(rank * per, (rank + 1) * per)
+    losses = tr.train_step(*[x[sl].cuda() for x in inputs], label[sl].cuda(), 0, 10)
+    tr.join()
+    torch.cuda.synchronize()
+    res = _collect(model, tr, losses)
+    res["feat_rows"] = (rank * per, (rank + 1) * per)
+    torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("which", ["m3ae", "modal3"])
+def test_two_rank_transformer_trainers_equal_global_batch(tmp_path, which):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_transformer, args=(r, port, str(tmp_path), which)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    model, tr, inputs, label = _build_transformer(which)                       # one process, whole batch
+    losses = tr.train_step(*[x.cuda() for x in inputs], label.cuda(), 0, 10)
+    tr.join()
+    torch.cuda.synchronize()
+    ref = _collect(model, tr, losses)
+    tags = [t for t, _g, _e in model.mla_encoders()]
+    for k in ["Pl", "head", "loss"] + ["loss_" + t for t in tags] + ["raw_" + t for t in tags] + ["proj_" + t for t in tags]:
+        assert torch.equal(r0[k], r1[k]), f"ranks must hold identical {k}"
+    for tag in tags:
+        assert_close(r0["loss_" + tag].reshape(()), ref["loss_" + tag].reshape(()), atol=2e-5, name=f"global loss {tag}")
+        assert_close(r0["raw_" + tag], ref["raw_" + tag], atol=1e-5, name=f"raw head grad {tag} (global batch)")
+        lo, hi = r1["feat_rows"]
+        assert_close(r1["feat_" + tag], ref["feat_" + tag][lo:hi], atol=2e-5, name=f"rank-1 features {tag}")
+        for k, g in ref["grads_" + tag].items():
+            assert_close_robust(r0["grads_" + tag][k], g, rel_l2=2e-4, elem_tol=1.0, frac=0.0, name=f"reduced grad {tag}.{k}")
+    # first modality: the projection has not fired yet (Q5), so its "projected" gradient is the raw one -> head update equal
+    assert_close(r0["proj_" + tags[0]], ref["proj_" + tags[0]], atol=1e-5, name="first-phase head gradient")

@@ -308,3 +308,72 @@ def test_device_feeder_delivers_batches_in_order():
     assert len(seen) == 7
     for (s, im, l), (hs, him, hl) in zip(seen, host):
         assert torch.equal(s.cpu(), hs) and torch.equal(im.cpu(), him) and torch.equal(l.cpu(), hl)
+
+
+def test_full_size_config1_step_properties():
+    """BASELINE configs[1] at its real size (CREMA-D shapes, batch 64) through whole steps, without a CPU oracle:
+    (1) the per-encoder stream pipeline equals the serialized trainer bit for bit after two steps;
+    (2) the two conv arithmetics agree on the north-star outputs of step 0 (logits, loss, raw and projected head gradient)
+        within 2e-4 -- they share nothing but the inputs, and each is pinned to the CPU oracle at batch 8 / 2;
+    (3) BatchNorm statistics, losses and parameters stay finite."""
+    seed, B = 7, 64
+    spec0, image0, label0 = [x.cuda() for x in inputs(seed, 0, B, (1024, 128), 3, (224, 224))]
+    spec1, image1, label1 = [x.cuda() for x in inputs(seed, 1, B, (1024, 128), 3, (224, 224))]
+    out = {}
+    for name, conv_math, overlap in (("f32_overlap", "f32", True), ("f32_serial", "f32", False), ("split_overlap", "split", True)):
+        model, tr, _ = build(seed, "as_intended", False, conv_math)
+        tr.set_overlap(overlap)
+        l0 = {k: v.clone() for k, v in tr.train_step(spec0, image0, label0, 0, 100).items()}
+        rec = {"out_a": tr.last["out_a"].clone(), "out_v": tr.last["out_v"].clone(), "raw_a": tr.last["head_grad_a_raw"].clone(),
+               "proj_v": tr.last["head_grad_v"].clone(), "loss0": l0}
+        l1 = tr.train_step(spec1, image1, label1, 1, 100)
+        tr.join()
+        torch.cuda.synchronize()
+        rec.update(loss1={k: v.clone() for k, v in l1.items()}, audio=model.audio_net.flat.clone(), visual=model.visual_net.flat.clone(),
+                   head=model.fusion_module.fc_out.flat.clone(), Pl=tr.gs_plugin.Pl.clone(), running=model.visual_net.running.clone(),
+                   mom=tr.optimizer.buf["visual"].clone())
+        out[name] = rec
+        for k in ("audio", "visual", "head", "Pl", "running", "mom"):
+            assert torch.isfinite(rec[k]).all(), (name, k)
+        assert (model.visual_net.running[model.visual_net._tot_bn:] > 0).all()          # running_var stays positive
+        del model, tr
+        torch.cuda.empty_cache()
+    a, b = out["f32_overlap"], out["f32_serial"]
+    for k in ("audio", "visual", "head", "Pl", "running", "mom", "out_a", "out_v", "proj_v"):
+        assert torch.equal(a[k], b[k]), f"stream pipeline changed {k}"
+    assert all(torch.equal(a["loss1"][k], b["loss1"][k]) for k in a["loss1"])
+    c = out["split_overlap"]
+    for k in ("out_a", "out_v", "raw_a", "proj_v"):
+        assert_close(c[k], a[k], atol=TOL, name=f"f32 vs split {k} (B=64)")
+    for k in ("loss", "loss_a", "loss_v"):
+        assert_close(c["loss0"][k], a["loss0"][k], atol=TOL, name=f"f32 vs split {k} (B=64)")
+
+
+def test_device_feeder_with_stream_pipeline_is_bitwise_equivalent():
+    """the feeder recycles a device slot as soon as the consuming step has been ENQUEUED on the caller's
+    stream, while the overlapped trainer's encoder chains (stem weight gradient reading the spectrogram) are still running
+    on their own streams.  Drive DeviceFeeder(depth=3) + the stream pipeline for 6 steps with distinct batches and no
+    host synchronisation, and compare with the serialized trainer fed from plain device tensors: bit for bit."""
+    from mla_hip import DeviceFeeder
+    seed, B, steps = 67, 4, 6
+    host = []
+    for s in range(steps):
+        spec, image, label = inputs(seed, s, B, (128, 64), 2, (64, 64))
+        host.append((spec.pin_memory(), image.pin_memory(), label.pin_memory()))
+    model_s, tr_s, _ = build(seed, "as_intended", False)
+    tr_s.keep_debug = False
+    tr_s.set_overlap(False)
+    for s, (spec, image, label) in enumerate(host):
+        tr_s.train_step(spec.cuda(), image.cuda(), label.cuda(), s, 10)
+    torch.cuda.synchronize()
+    model_f, tr_f, _ = build(seed, "as_intended", False)
+    tr_f.keep_debug = False
+    assert tr_f.overlap_forward
+    for s, (spec, image, label) in enumerate(DeviceFeeder(iter(host), depth=3)):
+        tr_f.train_step(spec, image, label, s, 10)                         # no .item(), no synchronize between steps
+    tr_f.join()
+    torch.cuda.synchronize()
+    for a, b in ((model_s.audio_net.flat, model_f.audio_net.flat), (model_s.visual_net.flat, model_f.visual_net.flat),
+                 (model_s.fusion_module.fc_out.flat, model_f.fusion_module.fc_out.flat), (tr_s.gs_plugin.Pl, tr_f.gs_plugin.Pl),
+                 (tr_s.optimizer.buf["audio"], tr_f.optimizer.buf["audio"])):
+        assert torch.equal(a, b)
