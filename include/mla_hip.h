@@ -158,6 +158,22 @@ int mla_colsum(const float* X, float* r, int B, int D, float scale, void* stream
 size_t mla_gs_ws_elems(int D, int C);
 int mla_gs_project(float* Pl, const float* r, float* G, int D, int C, float alpha, float* ws, void* stream);
 
+/* ---- OGM / OGM-GE gradient modulation (main.py:312-410, --modulation OGM | OGM_GE) ---------------------------------
+ * mla_ogm_coeff: score_m = sum_i softmax(out_m)[i][label_i] (row order), ratios and the coefficient of every modality
+ *   (main.py:373-384 for M = 2: {audio, visual}; 314-337 for M = 3: {audio, visual, text}) -> coeff[M] on the device;
+ *   info (nullable, 6 floats): scores at [0..M), ratios at [3..3+M).
+ * mla_ogm_modulate: for each segment (= one 4-D conv gradient; seg_desc int64 [n_seg][2] = {offset, numel} into `grad`,
+ *   device memory): grad = grad * *coeff, and with ge != 0 additionally + N(0, std + 1e-8), std = unbiased standard
+ *   deviation of the UNSCALED segment (main.py:397-400).  first_chunk (int [n_seg + 1], device): prefix sum of
+ *   ceil(numel / mla_ogm_chunk_elems()) per segment; total_chunks = first_chunk[n_seg].  Noise: Philox4x32-10 keyed by
+ *   `seed`, stream (step, segment), counter = element / 4 -> reproducible, independent of the launch geometry. */
+int mla_ogm_coeff(const float* out0, const float* out1, const float* out2, const int64_t* labels, int M, int B, int C,
+                  float alpha, float* coeff, float* info, void* stream);
+int mla_ogm_chunk_elems(void);
+size_t mla_ogm_ws_bytes(int total_chunks, int n_seg);
+int mla_ogm_modulate(float* grad, const int64_t* seg_desc, const int* first_chunk, int n_seg, int total_chunks,
+                     const float* coeff, int ge, uint64_t seed, uint64_t step, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- transformer encoders (M3AE, models/m3ae.py; CAV-MAE, models/cav_mae.py) ------------------- */
 /* nn.Linear on the gather-GEMM: y[g][y_off+r][:] = x[g][x_off+r][:] . w_kn (+ bias) (+ residual);
  * rows are `groups` x `rows` tokens taken at an offset inside groups of *_group_rows tokens (no copies for

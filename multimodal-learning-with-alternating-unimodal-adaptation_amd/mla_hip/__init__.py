@@ -9,6 +9,7 @@ from .encoder import ResNet18Encoder  # noqa: F401
 from .feed import DeviceFeeder  # noqa: F401
 from .model import AVClassifier, ConcatFusion, SharedHead  # noqa: F401
 from .m3ae import ConcatFusion3, M3AEClassifier, M3AEEncoder, Modal3Classifier  # noqa: F401
+from .modulation import OGM  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .plugin import GSPlugin  # noqa: F401
 from .protocol import CrossEntropyLoss, DataParallel, setup_seed, weight_init  # noqa: F401

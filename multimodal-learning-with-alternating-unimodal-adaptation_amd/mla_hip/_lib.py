@@ -57,6 +57,10 @@ PROTOTYPES = {
     "mla_ce_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "mla_head_bwd": (_I, [_P] * 6 + [_I, _I, _I, _F, _P]),
     "mla_scale_by_device_scalar": (_I, [_P, _P, _Z, _P]),
+    "mla_ogm_coeff": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "mla_ogm_chunk_elems": (_I, []),
+    "mla_ogm_ws_bytes": (_Z, [_I, _I]),
+    "mla_ogm_modulate": (_I, [_P, _P, _P, _I, _I, _P, _I, ctypes.c_uint64, ctypes.c_uint64, _P, _Z, _P]),
     "mla_colsum": (_I, [_P, _P, _I, _I, _F, _P]),
     "mla_gs_ws_elems": (_Z, [_I, _I]),
     "mla_gs_project": (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),

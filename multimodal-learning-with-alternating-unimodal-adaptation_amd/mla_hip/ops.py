@@ -501,3 +501,27 @@ def eval_fuse(outs, labels, counts, weights_out, dynamic: bool, alphas, stream: 
 
 def bn_invstd(var, invstd, eps: float = BN_EPS, stream: Optional[int] = None):
     check(_lib.load().mla_bn_invstd(_p(var), _p(invstd), var.numel(), eps, stream or cur_stream()), "mla_bn_invstd")
+
+
+# ---- OGM / OGM-GE gradient modulation (main.py:312-410) ---------------------------------------------------------------------
+def ogm_coeff(outs, labels, alpha: float, coeff, info=None, stream: Optional[int] = None):
+    M = len(outs)
+    B, C = outs[0].shape
+    ptrs = [_p(t) for t in outs] + [None] * (3 - M)
+    check(_lib.load().mla_ogm_coeff(ptrs[0], ptrs[1], ptrs[2], _p(labels, torch.int64), M, B, C, alpha, _p(coeff), _p(info),
+                                    stream or cur_stream()), "mla_ogm_coeff")
+
+
+def ogm_chunk_elems() -> int:
+    return int(_lib.load().mla_ogm_chunk_elems())
+
+
+def ogm_ws_bytes(total_chunks: int, n_seg: int) -> int:
+    return int(_lib.load().mla_ogm_ws_bytes(total_chunks, n_seg))
+
+
+def ogm_modulate(grad, seg_desc, first_chunk, n_seg: int, total_chunks: int, coeff, ge: bool, seed: int, step: int, ws,
+                 stream: Optional[int] = None):
+    check(_lib.load().mla_ogm_modulate(_p(grad), _p(seg_desc, torch.int64), _p(first_chunk, torch.int32), n_seg, total_chunks,
+                                       _p(coeff), int(ge), seed, step, _p(ws, torch.uint8) if ws is not None else None,
+                                       ws.numel() if ws is not None else 0, stream or cur_stream()), "mla_ogm_modulate")

@@ -768,3 +768,51 @@ def valid_batch(outs: List[torch.Tensor], label: torch.Tensor, n_classes: int, d
             if pr[i] == label[i]:
                 counts[1 + k, label[i]] += 1
     return [float(x) for x in w], counts
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OGM / OGM-GE gradient modulation.  main.py:312-410, non --gs_flag branch.
+# ---------------------------------------------------------------------------------------------------------------------
+def ogm_coefficients(outs: List[torch.Tensor], label: torch.Tensor, alpha: float):
+    """main.py:373-384 (two modalities: outs = [out_a, out_v]) / main.py:314-337 (three: [out_a, out_v, out_t]).
+    Returns (coeffs, scores, ratios) as python floats / 0-dim tensors exactly as the reference forms them: softmax over
+    dim 1 (main.py:131), python sum() over the rows in order, tanh / relu modules on 0-dim tensors."""
+    softmax, relu, tanh = torch.nn.Softmax(dim=1), torch.nn.ReLU(inplace=False), torch.nn.Tanh()
+    scores = [sum([softmax(o)[i][label[i]] for i in range(o.size(0))]) for o in outs]
+    one = torch.tensor(1.0)
+    if len(outs) == 2:
+        score_a, score_v = scores
+        ratio_v = score_v / score_a                                   # :376
+        ratio_a = 1 / ratio_v                                         # :377
+        if ratio_v > 1:                                               # :379-384
+            coeffs = [one, 1 - tanh(alpha * relu(ratio_v))]
+        else:
+            coeffs = [1 - tanh(alpha * relu(ratio_a)), one]
+        ratios = [ratio_a, ratio_v]
+    else:
+        score_a, score_v, score_t = scores
+        ratio_v = score_v / (score_a + score_t)                       # :319-321
+        ratio_a = score_a / (score_v + score_t)
+        ratio_t = score_t / (score_v + score_a)
+        if ratio_v > 1:                                               # :323-337
+            coeffs = [one, 1 - tanh(alpha * relu(ratio_v)), one]
+        elif ratio_t > 1:
+            coeffs = [one, one, 1 - tanh(alpha * relu(ratio_t))]
+        else:
+            coeffs = [1 - tanh(alpha * relu(ratio_a)), one, one]
+        ratios = [ratio_a, ratio_v, ratio_t]
+    return [torch.as_tensor(c, dtype=torch.float32) for c in coeffs], scores, ratios
+
+
+def ogm_modulate(grads: Dict[str, torch.Tensor], coeff: torch.Tensor, mode: str, generator: Optional[torch.Generator] = None):
+    """main.py:394-408 for one encoder: every 4-D gradient is scaled (OGM) or scaled and perturbed with N(0, std + 1e-8)
+    of the unscaled gradient (OGM_GE); other gradients are untouched.  Returns the new dict."""
+    out = {}
+    for k, g in grads.items():
+        if g.dim() != 4:
+            out[k] = g
+        elif mode == "OGM_GE":
+            out[k] = g * coeff + torch.zeros_like(g).normal_(0, g.std().item() + 1e-8, generator=generator)   # :397-400
+        else:
+            out[k] = g * coeff                                                                                 # :401-402
+    return out

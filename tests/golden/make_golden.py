@@ -391,6 +391,107 @@ def run_eval_case(B, spec_hw, T, img_hw, seed):
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+
+def run_ogm_kat(seed=81, B=6, spec_hw=(96, 64), T=2, img_hw=(64, 64)):
+    """OGM / OGM-GE (main.py:268-410, the non --gs_flag branch).  The modulation code is inline in
+    `train_epoch` (main.py is not importable here), so this restates main.py:297-311 and 373-408 around the REFERENCE's
+    own modules: `AVClassifier` with gs_flag=False (ConcatFusion(1024 -> 6), basic_model.py:31-34) gives a, v, out;
+    out_a / out_v are the half-weight products of main.py:297-301; `loss.backward()` gives the encoder gradients; the
+    coefficients and the scaled gradients use torch's nn.Softmax / nn.Tanh / nn.ReLU modules as main.py:131-133 does.
+    Fixture: logits, labels, coefficients / scores / ratios for alpha in {0.1, 0.3, 0.8} and both orderings (audio- and
+    visual-dominant), plus two conv gradients before / after OGM scaling and the noise scale `grad.std() + 1e-8` OGM_GE uses."""
+    print("== OGM / OGM-GE known-answer vectors")
+
+    class A(_Args):
+        gs_flag = False
+    torch.manual_seed(0)
+    model = AVClassifier(A())
+    pa, pv = O.make_resnet18_params("audio", seed), O.make_resnet18_params("visual", seed + 1)
+    model.audio_net.load_state_dict(pa)
+    model.visual_net.load_state_dict(pv)
+    hd = O.make_head_params(1024, 6, seed + 2)
+    model.fusion_module.fc_out.load_state_dict(hd)
+    model = torch.nn.DataParallel(model)
+    model.train()
+    spec = O.portable_normal(seed, (B,) + spec_hw, stream=1, mean=-5.081, std=4.4849)
+    image = O.portable_normal(seed, (B, 3, T) + img_hw, stream=2)
+    label = O.portable_labels(seed, B, 6)
+    softmax, relu, tanh = nn.Softmax(dim=1), nn.ReLU(inplace=True), nn.Tanh()                    # main.py:131-133
+    a, v, out = model(spec.unsqueeze(1).float(), image.float())                                  # :273
+    weight_size = model.module.fusion_module.fc_out.weight.size(1)                               # :297
+    out_v = (torch.mm(v, torch.transpose(model.module.fusion_module.fc_out.weight[:, weight_size // 2:], 0, 1))
+             + model.module.fusion_module.fc_out.bias / 2)                                       # :298-299
+    out_a = (torch.mm(a, torch.transpose(model.module.fusion_module.fc_out.weight[:, :weight_size // 2], 0, 1))
+             + model.module.fusion_module.fc_out.bias / 2)                                       # :301-302
+    loss = nn.CrossEntropyLoss()(out, label)                                                     # :305
+    loss.backward()                                                                              # :310
+    fx = {"meta": np.array([B, 6, seed], dtype=np.int64), "label": label.numpy()}
+    cases = {"ref": (out_a.detach(), out_v.detach()), "swapped": (out_v.detach(), out_a.detach()),
+             "sharp": (out_a.detach() * 4.0, out_v.detach() * 0.25)}
+    for cname, (oa, ov) in cases.items():
+        fx[f"{cname}.out_a"], fx[f"{cname}.out_v"] = oa.numpy(), ov.numpy()
+        for alpha in (0.1, 0.3, 0.8):
+            score_v = sum([softmax(ov)[i][label[i]] for i in range(ov.size(0))])                 # :373
+            score_a = sum([softmax(oa)[i][label[i]] for i in range(oa.size(0))])                 # :374
+            ratio_v = score_v / score_a                                                          # :376
+            ratio_a = 1 / ratio_v                                                                # :377
+            if ratio_v > 1:                                                                      # :379-384
+                coeff_v = 1 - tanh(alpha * relu(ratio_v))
+                coeff_a = 1
+            else:
+                coeff_a = 1 - tanh(alpha * relu(ratio_a))
+                coeff_v = 1
+            cf, sc, ra = O.ogm_coefficients([oa, ov], label, alpha)
+            close(f"ogm.{cname}.a{alpha}.coeff_a", cf[0], torch.as_tensor(coeff_a, dtype=torch.float32), rtol=1e-6, atol=1e-7)
+            close(f"ogm.{cname}.a{alpha}.coeff_v", cf[1], torch.as_tensor(coeff_v, dtype=torch.float32), rtol=1e-6, atol=1e-7)
+            fx[f"{cname}.alpha{alpha}"] = np.array([float(coeff_a), float(coeff_v), float(score_a), float(score_v), float(ratio_a),
+                                                   float(ratio_v)], dtype=np.float64)
+    # three modalities (main.py:314-337): a third set of logits stands in for out_t
+    out_t = O.portable_normal(seed, (B, 6), stream=7)
+    fx["three.out_t"] = out_t.numpy()
+    for alpha in (0.3,):
+        oa, ov = cases["ref"]
+        for tag, (x0, x1, x2) in {"avt": (oa, ov, out_t), "tva": (out_t * 3, ov, oa)}.items():
+            score_v = sum([softmax(x1)[i][label[i]] for i in range(B)])
+            score_a = sum([softmax(x0)[i][label[i]] for i in range(B)])
+            score_t = sum([softmax(x2)[i][label[i]] for i in range(B)])
+            ratio_v = score_v / (score_a + score_t)
+            ratio_a = score_a / (score_v + score_t)
+            ratio_t = score_t / (score_v + score_a)
+            if ratio_v > 1:
+                c3 = [1, 1 - tanh(alpha * relu(ratio_v)), 1]
+            elif ratio_t > 1:
+                c3 = [1, 1, 1 - tanh(alpha * relu(ratio_t))]
+            else:
+                c3 = [1 - tanh(alpha * relu(ratio_a)), 1, 1]
+            cf, _sc, _ra = O.ogm_coefficients([x0, x1, x2], label, alpha)
+            for k in range(3):
+                close(f"ogm.three.{tag}.coeff{k}", cf[k], torch.as_tensor(c3[k], dtype=torch.float32), rtol=1e-6, atol=1e-7)
+            fx[f"three.{tag}"] = np.array([float(c) for c in c3] + [float(ratio_a), float(ratio_v), float(ratio_t)], dtype=np.float64)
+    # gradient modulation on the reference's own gradients (main.py:394-408), alpha = 0.3 on the "ref" logits
+    coeff_a, coeff_v = [torch.tensor(float(x), dtype=torch.float32) for x in fx["ref.alpha0.3"][:2]]
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    for name, parms in model.named_parameters():
+        layer = str(name).split('.')[1]                                                          # :395
+        if 'audio' in layer and len(parms.grad.size()) == 4:                                     # :397
+            parms.grad *= coeff_a                                                                # :402 (OGM)
+        if 'visual' in layer and len(parms.grad.size()) == 4:
+            parms.grad *= coeff_v
+    mod_a = O.ogm_modulate({k[len("module.audio_net."):]: g for k, g in grads.items() if k.startswith("module.audio_net.")}, coeff_a, "OGM")
+    for k, gref in mod_a.items():
+        close(f"ogm.scaled.audio.{k}", gref, dict(model.named_parameters())["module.audio_net." + k].grad, rtol=0, atol=0)
+    for enc in ("audio_net", "visual_net"):
+        for k in ("conv1.weight", "layer1.0.conv1.weight", "bn1.weight"):
+            g0, g1 = grads[f"module.{enc}.{k}"], dict(model.named_parameters())[f"module.{enc}.{k}"].grad
+            fx[f"grad.{enc}.{k}"], fx[f"ogm.{enc}.{k}"] = g0.numpy(), g1.numpy()
+            if g0.dim() == 4:
+                fx[f"ge_std.{enc}.{k}"] = np.float64(g0.std().item() + 1e-8)                     # :399 noise scale
+    fx["spec_hw"], fx["img"] = np.array(spec_hw), np.array((T,) + img_hw)
+    path = os.path.join(HERE, "ogm_kat.npz")
+    np.savez_compressed(path, **fx)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     keep = ("conv1.weight", "bn1.weight", "bn1.bias", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight",
@@ -403,4 +504,5 @@ if __name__ == "__main__":
     run_gs_kat(768, 4, 32, 3, seed=23)
     run_m3ae_case("small", 3, 2, 1000, 11, 2, seed=61)
     run_eval_case(16, (128, 64), 2, (96, 96), seed=71)
+    run_ogm_kat()
     print("all oracle-vs-reference checks passed")

@@ -162,3 +162,36 @@ def test_oracle_eval_vs_reference_golden(golden_dir):
         w, counts = O.valid_batch([torch.from_numpy(fx["out_a"]), torch.from_numpy(fx["out_v"])], label, 6, dyn, [0.5, 0.5])
         assert np.allclose(w, fx[f"{tag}.weights"], atol=1e-6) and (counts.numpy() == fx[f"{tag}.counts"]).all()
         assert abs(sum(w) - 1.0) < 1e-6 and int(counts[0].sum()) == B
+
+
+def test_ogm_oracle_vs_reference_vectors(golden_dir):
+    """OGM / OGM-GE: the oracle's restatement of main.py:314-337, 373-408 against the vectors make_golden.py
+    produced around the reference's modules (coefficients for both dominance orders, three alphas, three modalities; OGM
+    scaling of the reference's own conv gradients; the OGM-GE noise scale grad.std() + 1e-8)."""
+    fx = np.load(os.path.join(golden_dir, "ogm_kat.npz"))
+    label = torch.from_numpy(fx["label"])
+    for cname in ("ref", "swapped", "sharp"):
+        oa, ov = torch.from_numpy(fx[f"{cname}.out_a"]), torch.from_numpy(fx[f"{cname}.out_v"])
+        for alpha in (0.1, 0.3, 0.8):
+            want = fx[f"{cname}.alpha{alpha}"]
+            cf, sc, ra = O.ogm_coefficients([oa, ov], label, alpha)
+            got = [float(cf[0]), float(cf[1]), float(sc[0]), float(sc[1]), float(ra[0]), float(ra[1])]
+            assert np.allclose(got, want, rtol=1e-6, atol=1e-7), (cname, alpha, got, want)
+    oa, ov, ot = torch.from_numpy(fx["ref.out_a"]), torch.from_numpy(fx["ref.out_v"]), torch.from_numpy(fx["three.out_t"])
+    for tag, outs in (("avt", [oa, ov, ot]), ("tva", [ot * 3, ov, oa])):
+        cf, _sc, ra = O.ogm_coefficients(outs, label, 0.3)
+        got = [float(c) for c in cf] + [float(r) for r in ra]
+        assert np.allclose(got, fx[f"three.{tag}"], rtol=1e-6, atol=1e-7), (tag, got)
+    coeff = {"audio_net": torch.tensor(float(fx["ref.alpha0.3"][0])), "visual_net": torch.tensor(float(fx["ref.alpha0.3"][1]))}
+    for enc in ("audio_net", "visual_net"):
+        grads = {k: torch.from_numpy(fx[f"grad.{enc}.{k}"]) for k in ("conv1.weight", "layer1.0.conv1.weight", "bn1.weight")}
+        out = O.ogm_modulate(grads, coeff[enc], "OGM")
+        for k in grads:
+            assert torch.equal(out[k], torch.from_numpy(fx[f"ogm.{enc}.{k}"])), (enc, k)        # 4-D scaled, 1-D untouched
+        g = torch.Generator().manual_seed(1)
+        ge = O.ogm_modulate(grads, coeff[enc], "OGM_GE", generator=g)
+        for k in ("conv1.weight", "layer1.0.conv1.weight"):
+            noise = ge[k] - grads[k] * coeff[enc]
+            sd = float(fx[f"ge_std.{enc}.{k}"])
+            assert abs(noise.std().item() - sd) < 0.05 * sd and abs(noise.mean().item()) < 0.1 * sd
+        assert torch.equal(ge["bn1.weight"], grads["bn1.weight"])
