@@ -179,12 +179,17 @@ class Evaluator:
     """`valid()` of the reference under --gs_flag (main.py:486-679): eval-mode encoders, shared head applied to every
     modality, fixed (av_alpha | a/v/t_alpha) or entropy-gated (--dynamic, main.py:65-106) fusion, per-class accuracy
     counters -- kept on the device (one fusion/arg-max kernel per batch instead of the per-sample .cpu() loop of
-    main.py:659-676).  Data parallel note: the dynamic weights depend on the batch composition, so
-    evaluation must see the same global batches as the reference; this class evaluates rank-local batches."""
+    main.py:659-676).  Data parallel: the dynamic weights are ONE scalar per modality computed over the whole
+    batch (softmax over dim 0), so they depend on the batch composition; the reference evaluates the global batch on GPU 0
+    (DataParallel gathers the features, main.py:624-639).  With an active `comm` every rank all-gathers the (B_local, C)
+    logits and labels of all ranks (rank order = the order DataParallel scatters / gathers in) on the head communicator
+    and runs the fusion kernel on the global batch: every rank holds the same counters and weights as a single process
+    evaluating the concatenated batch."""
 
     def __init__(self, model, dynamic: bool = False, av_alpha: float = 0.5, a_alpha: float = 0.35, v_alpha: float = 0.25,
-                 t_alpha: float = 0.4):
+                 t_alpha: float = 0.4, comm: Optional[Comm] = None):
         self.model = model
+        self.comm = comm if comm is not None else Comm()
         self.head = model.fusion_module.fc_out
         self.M = len(model.mla_encoders())
         self.C = self.head.out_features
@@ -207,7 +212,12 @@ class Evaluator:
             inputs = (spec.float(), image.float())
         feats = self.model.forward_raw(*inputs)
         outs = [self.head.logits(f, slot="eval_" + str(k)) for k, f in enumerate(feats)]
-        ops.eval_fuse(outs, label, self.counts, self.weights, self.dynamic, self.alphas)
+        if self.comm.active:                                         # global batch (Q9): (world * B_local, C) in rank order
+            g_outs = [self.comm.allgather_rows(o) for o in outs]
+            g_label = self.comm.allgather_rows(label.contiguous())
+            ops.eval_fuse(g_outs, g_label, self.counts, self.weights, self.dynamic, self.alphas)
+        else:
+            ops.eval_fuse(outs, label, self.counts, self.weights, self.dynamic, self.alphas)
         return outs
 
     def result(self):

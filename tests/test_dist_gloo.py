@@ -151,3 +151,49 @@ def test_two_rank_exchange_equals_dataparallel_semantics(tmp_path):
             assert err < 1e-5, (name, k, err)
     assert torch.allclose(full["Pl"], ref["Pl"], atol=1e-7, rtol=1e-4)
     assert torch.equal(other["Pl"], full["Pl"])
+
+
+# ---- evaluation under data parallel: --dynamic weights need the GLOBAL batch ------------------------------------
+def _eval_worker(rank, port, outdir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from mla_hip.dist import Comm
+    comm = Comm()
+    B, C = 8, 6
+    outs = [O.portable_normal(300 + m, (B, C), stream=1, std=1.5) for m in range(2)]
+    label = O.portable_labels(300, B, C)
+    per = B // WORLD
+    sl = slice(rank * per, (rank + 1) * per)
+    g_outs = [comm.allgather_rows(o[sl].contiguous()) for o in outs]             # what Evaluator.update exchanges
+    g_label = comm.allgather_rows(label[sl].contiguous())
+    w_glob, c_glob = O.valid_batch(g_outs, g_label, C, True, [0.5, 0.5])
+    w_loc, _ = O.valid_batch([o[sl] for o in outs], label[sl], C, True, [0.5, 0.5])
+    torch.save({"w_glob": torch.tensor(w_glob), "c_glob": c_glob, "w_loc": torch.tensor(w_loc), "g_label": g_label},
+               os.path.join(outdir, f"eval{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_dynamic_eval_equals_global_batch(tmp_path):
+    """main.py:65-70, 640-646: the entropy weights are computed over the batch axis, so a rank-local evaluation differs from
+    the reference's (global-batch, GPU 0) one; after the all-gather both ranks reproduce the single-process result."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, port, str(tmp_path))) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=200)
+        assert p.exitcode == 0
+    B, C = 8, 6
+    outs = [O.portable_normal(300 + m, (B, C), stream=1, std=1.5) for m in range(2)]
+    label = O.portable_labels(300, B, C)
+    w_ref, c_ref = O.valid_batch(outs, label, C, True, [0.5, 0.5])
+    r0 = torch.load(tmp_path / "eval0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "eval1.pt", weights_only=True)
+    for r in (r0, r1):
+        assert torch.equal(r["g_label"], label)
+        assert torch.allclose(r["w_glob"], torch.tensor(w_ref), atol=1e-7)
+        assert torch.equal(r["c_glob"], c_ref)
+    assert not torch.allclose(r0["w_loc"], torch.tensor(w_ref), atol=1e-4), "the rank-local weights differ: the exchange is needed"

@@ -193,3 +193,56 @@ def test_two_rank_transformer_trainers_equal_global_batch(tmp_path, which):
             assert_close_robust(r0["grads_" + tag][k], g, rel_l2=2e-4, elem_tol=1.0, frac=0.0, name=f"reduced grad {tag}.{k}")
     # first modality: the projection has not fired yet (Q5), so its "projected" gradient is the raw one -> head update equal
     assert_close(r0["proj_" + tags[0]], ref["proj_" + tags[0]], atol=1e-5, name="first-phase head gradient")
+
+
+# ---- evaluation: --dynamic fusion on the global batch (Q9), real Evaluator on two ranks ---------------------------------------
+def _eval_worker(rank, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    from mla_hip import Comm, Evaluator
+    from test_eval_gpu import _model
+    model = _model(71)
+    ev = Evaluator(model, dynamic=True, comm=Comm())
+    spec, image, label = _eval_inputs()
+    per = spec.shape[0] // WORLD
+    sl = slice(rank * per, (rank + 1) * per)
+    ev.update(spec[sl].cuda(), image[sl].cuda(), label[sl].cuda())
+    torch.cuda.synchronize()
+    torch.save({"counts": ev.counts.cpu(), "weights": ev.weights.cpu()}, os.path.join(outdir, f"ev{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _eval_inputs(B=8):
+    spec = O.portable_normal(80, (B, 128, 64), stream=1, mean=-5.081, std=4.4849)
+    image = O.portable_normal(80, (B, 3, 2, 96, 96), stream=2)
+    return spec, image, O.portable_labels(80, B, 6)
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_dynamic_eval_equals_single_process_global_batch(tmp_path):
+    """Eval-mode BatchNorm uses running statistics, so the logits of a sample do not depend on its shard: two ranks that
+    all-gather their logits must reproduce the single-process evaluation of the whole batch exactly (counters) / to 1e-6
+    (entropy weights: one scalar per modality over the GLOBAL batch, main.py:65-70)."""
+    from mla_hip import Evaluator
+    from test_eval_gpu import _model
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, port, str(tmp_path))) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=400)
+        assert p.exitcode == 0
+    spec, image, label = _eval_inputs()
+    ev = Evaluator(_model(71), dynamic=True)
+    ev.update(spec.cuda(), image.cuda(), label.cuda())
+    torch.cuda.synchronize()
+    r0 = torch.load(tmp_path / "ev0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "ev1.pt", weights_only=True)
+    for r in (r0, r1):
+        assert torch.equal(r["counts"], ev.counts.cpu())
+        assert_close(r["weights"], ev.weights, atol=1e-6, name="global-batch entropy weights")
+    assert int(r0["counts"][:6].sum()) == spec.shape[0]                       # every rank counted the whole batch
