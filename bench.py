@@ -9,9 +9,10 @@ Workload (BASELINE.json configs[1]; configs[2] for N>1): CREMA-D, --gs_flag, Res
 per-GPU batch 64 of synthetic (1x1024x128 spectrogram + 3x3x224x224 frames), fp32, weak scaling.
 One "step" = joint encoder forward + 2 x {head fwd/CE/bwd, encoder backward, GS projection, SGD}.
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 with
-`roofline` (dominant kernel = the fp32-MFMA implicit-GEMM convolution, HIP events in a serialized pass after the timed region),
-`alt_math` (the same steps with the other conv arithmetic: --math f32 = exact fp32 MFMA, the default; split = exact
-3-way bf16 operand split, 6 bf16 MFMAs per fp32 product, fp32-equivalent accuracy; N=1 only)
+`roofline` (dominant kernel = the implicit-GEMM convolution of the selected arithmetic, HIP events in a serialized pass after the
+timed region; peak = bf16 MFMA rate / 6 products for split, the fp32 MFMA rate for f32),
+`alt_math` (the same steps with the other conv arithmetic: --math split, the shipped default = exact 3-way bf16 operand
+split, 6 bf16 MFMAs per fp32 product, fp32 in / out / accumulate, fp32-equivalent accuracy; f32 = the fp32 MFMA; N=1 only)
 and `cpu_baseline` (the CPU oracle = "port" of the reference path, timed on this host's cores, N=1 only).
 """
 import argparse
@@ -99,7 +100,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="disable the per-encoder stream pipeline (serialized kernels)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with the other conv arithmetic (N=1 only)")
-    ap.add_argument("--math", choices=["f32", "split"], default=os.environ.get("MLA_CONV_MATH", "f32"),
+    ap.add_argument("--math", choices=["f32", "split"], default=os.environ.get("MLA_CONV_MATH", "split"),
                     help="conv forward/dgrad arithmetic: f32 = exact fp32 MFMA; split = exact 3-way bf16 operand split, "
                          "6 bf16 MFMAs per fp32 product (fp32-equivalent accuracy, see DESIGN.md)")
     a = ap.parse_args()
@@ -220,11 +221,14 @@ def main() -> None:
         kname = ("igemm_split_kernel (conv forward + input gradient, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; "
                  "peak = bf16 MFMA rate / 6)") if split else "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)"
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01f_igemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_igemm_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01f_igemm_traffic.json")
         if os.path.exists(tpath):     # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, per conv call
             tj = json.load(open(tpath))
             traffic = round(tj["split" if split else "f32"]["hbm_bytes_per_call"])
-            traffic_src = "profiles/r01f_igemm_traffic.json: " + tj["method"] + "; " + tj["note"]
+            traffic_src = "profiles/" + os.path.basename(tpath) + " (PMC counters cannot be read inside this process; measured by " \
+                          "separate rocprofv3 --pmc passes over this same command): " + tj["method"] + "; " + tj["note"]
         per_kind = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
                         "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items() if k.startswith("conv")}
         # HBM family: BatchNorm forward / backward against 8 TB/s; `achieved` = algorithmic bytes / time
@@ -262,7 +266,8 @@ def main() -> None:
                       "encoder_gradients": "flat 44.7 MB buffer per encoder, 16 MB buckets, async all-reduce on RCCL's stream"},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "frac": round(achieved / peak, 4), "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": traffic,
                          "avg_launch_ms": round(ig["ms"] / max(ig["launches"], 1), 4),
                          "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2),
                          "measured": "HIP events around every conv launch over %d steps run right after the timed region "

@@ -10,7 +10,8 @@ MI355X-first host design, not a module-by-module port:
     once (288 GB of HBM: nothing is recomputed, nothing is allocated in steady state);
   * BatchNorm statistics come out of the conv epilogue; ReLU masks and residual adds ride in the
     dgrad / BN-apply epilogues, so no standalone element-wise kernels exist;
-  * conv_math selects the arithmetic of the forward / input-gradient contractions of the 64..512-channel convs:
+  * conv_math selects the arithmetic of the forward / input-gradient / weight-gradient contractions of the 64..512-channel
+    convs (default "split", $MLA_CONV_MATH overrides):
     "f32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = fp32 operands split exactly into three bf16 terms,
     six products on v_mfma_f32_32x32x16_bf16 (fp32 in / out / accumulate, same error against fp64; the conv weights
     are re-split once per forward).  The stem (1 / 3 input channels) always runs on the fp32 MFMA.
@@ -26,6 +27,12 @@ import torch
 from . import ops
 from ._lib import MLAHipError
 from .module import BatchNorm2dHolder, Conv2dHolder, FlatModule
+
+
+# Shipped default arithmetic of the conv / Linear contractions: "split" = every fp32 operand split exactly into three
+# bf16 terms, six bf16 MFMAs per fp32 product, fp32 accumulate -- fp32 in / out, error against fp64 no larger than the fp32
+# MFMA's (tests/test_ops_gpu.py::test_conv_split_is_not_reduced_precision), 1.2-1.3x the throughput.  "f32" = v_mfma_f32_32x32x2_f32.
+DEFAULT_CONV_MATH = "split"
 
 
 def conv_specs(modality: str) -> List[Tuple[str, int, int, int, int, int]]:
@@ -64,7 +71,7 @@ class ResNet18Encoder(FlatModule):
     def __init__(self, modality: str, device="cuda", seed: Optional[int] = None, conv_math: Optional[str] = None):
         super().__init__()
         self.modality = modality
-        self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", "f32")
+        self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", DEFAULT_CONV_MATH)
         if self.conv_math not in ("f32", "split"):
             raise MLAHipError(f"conv_math must be 'f32' or 'split', got {self.conv_math!r}")
         self.device = torch.device(device)

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import MLAHipError
+from .encoder import DEFAULT_CONV_MATH
 from .model import ConcatFusion, N_CLASSES, SharedHead, _Classifier
 from .module import FlatModule, Holder
 
@@ -63,7 +64,7 @@ class M3AEEncoder(FlatModule):
         if kind not in ("text", "image", "audio"):
             raise ValueError("kind must be 'text', 'image' or 'audio'")
         super().__init__()
-        self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", "f32")     # arithmetic of the Linear GEMMs (encoder.py)
+        self.conv_math = conv_math or os.environ.get("MLA_CONV_MATH", DEFAULT_CONV_MATH)     # arithmetic of the Linear GEMMs (encoder.py)
         if self.conv_math not in ("f32", "split"):
             raise MLAHipError(f"conv_math must be 'f32' or 'split', got {self.conv_math!r}")
         self.split = self.conv_math == "split"

@@ -95,6 +95,7 @@ class ConcatFusion(nn.Module):
 
 class _Classifier(nn.Module):
     """Shared protocol behaviour of AVClassifier / M3AEClassifier / Modal3Classifier."""
+    side_streams = True
 
     @property
     def module(self):
@@ -105,6 +106,10 @@ class _Classifier(nn.Module):
         if torch.is_grad_enabled() and self.training:
             if not hasattr(enc, "_anchor"):
                 enc._anchor = make_anchor(self.device)
+                # protocol path: the weight-gradient GEMMs of a backward run on a side stream beside the dgrad -> BN-backward
+                # chain (joined before the gradients are published), like in MLATrainer's pipeline
+                if self.side_streams and getattr(enc, "wgrad_stream", 0) is None and self.device.type == "cuda":
+                    enc.wgrad_stream = torch.cuda.Stream(device=self.device)
             return EncoderFeature.apply(enc._anchor, enc, run, B, D)
         out = torch.empty((B, D), device=self.device, dtype=torch.float32)
         run(out)

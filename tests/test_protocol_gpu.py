@@ -97,14 +97,15 @@ def inputs(seed, s, B, spec_hw, T, img_hw):
     return spec.cuda(), image.cuda(), label.cuda()
 
 
+@pytest.mark.parametrize("conv_math", ["split", "f32"])
 @pytest.mark.parametrize("criterion_kind,wrapper", [("mla", "mla"), ("torch", "torch")])
 @pytest.mark.parametrize("tag", ["small_intended", "small_published", "small_legacy"])
-def test_reference_loop_verbatim_vs_golden(tag, criterion_kind, wrapper, golden_dir):
+def test_reference_loop_verbatim_vs_golden(tag, criterion_kind, wrapper, conv_math, golden_dir):
     import mla_hip
     fx = np.load(os.path.join(golden_dir, f"mla_{tag}.npz"))
     B, sh, sw, T, ih, iw, steps, seed, ldl = [int(v) for v in fx["meta"]]
     gs_mode, legacy = str(fx["gs_mode"]), bool(int(fx["legacy"]))
-    model, optimizer, gs_plugin = build_protocol(seed, gs_mode, wrapper=wrapper)
+    model, optimizer, gs_plugin = build_protocol(seed, gs_mode, conv_math=conv_math, wrapper=wrapper)
     criterion = mla_hip.CrossEntropyLoss() if criterion_kind == "mla" else nn.CrossEntropyLoss()   # main.py:130
     model.train()
     for s in range(steps):
