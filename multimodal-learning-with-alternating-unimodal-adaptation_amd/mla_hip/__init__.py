@@ -4,6 +4,7 @@ Importing the package does not touch the GPU; the first op loads libmla_hip.so a
 MLAHipError if it is missing (there is no CPU or eager fallback).
 """
 from ._lib import MLAHipError, LIB_PATH  # noqa: F401
+from .data import NpyBatcher, load_fbank, load_token  # noqa: F401
 from .dist import Comm  # noqa: F401
 from .encoder import ResNet18Encoder  # noqa: F401
 from .feed import DeviceFeeder  # noqa: F401
