@@ -25,7 +25,7 @@ static int bn_tile_rows(int M) {
 // Every partial buffer carries a scratch tail for the two-stage reduction (declared in bn.hip, used by the conv too).
 extern "C" size_t mla_bn_partial_scratch_elems(int C) { return bn_red_scratch_floats(C); }
 extern "C" size_t mla_bn_stats_partial_elems(int M, int C) {
-  return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C + bn_red_scratch_floats(C);
+  return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C * 2 + bn_red_scratch_floats(C);     // forward statistics: fp64 partials
 }
 extern "C" size_t mla_bn_bwd_ws_elems(int M, int C) { return (size_t)cdiv(M, bn_tile_rows(M)) * 2 * C + bn_red_scratch_floats(C); }
 
@@ -45,6 +45,39 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   if (MODE == 1) {
     mu = reinterpret_cast<const f32x4*>(mean)[cg];
     is = reinterpret_cast<const f32x4*>(invstd)[cg];
+  }
+  if (MODE == 0) {   // forward statistics: everything in fp64 (x * x is exact there), see the conv epilogue in igemm_common.h
+    double d0[4] = {0.0, 0.0, 0.0, 0.0}, d1[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      const f32x4 xv = reinterpret_cast<const f32x4*>(x)[(size_t)r * c4n + cg];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double v = (double)xv[e];
+        d0[e] += v;
+        d1[e] += v * v;
+      }
+    }
+    __shared__ double redd[2][4][256];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      redd[0][e][threadIdx.x] = d0[e];
+      redd[1][e][threadIdx.x] = d1[e];
+    }
+    __syncthreads();
+    if (rl == 0) {
+      double* pd = reinterpret_cast<double*>(partial);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double a = d0[e], q = d1[e];
+        for (int k = 1; k < nrl; ++k) {
+          a += redd[0][e][k * c4n + cg];
+          q += redd[1][e][k * c4n + cg];
+        }
+        pd[((size_t)blockIdx.x * 2 + 0) * C + cg * 4 + e] = a;
+        pd[((size_t)blockIdx.x * 2 + 1) * C + cg * 4 + e] = q;
+      }
+    }
+    return;
   }
   for (int r = r0 + rl; r < r1; r += nrl) {
     const size_t idx = (size_t)r * c4n + cg;
@@ -85,7 +118,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
 static int bn_red_chunks(int tiles) { int s = cdiv(tiles, 64); return s < 1 ? 1 : (s > BN_RED_MAXS ? BN_RED_MAXS : s); }
 static size_t bn_red_scratch_floats(int C) { return (size_t)BN_RED_MAXS * 2 * C * 2 + 2; }   // doubles, as floats (+ alignment)
 
-__global__ __launch_bounds__(256) void bn_tiles_stage1_kernel(const float* __restrict__ partial, int tiles, int C,
+template <typename PT>   // PT = double: forward statistics partials; float: backward (sum g, sum g * xhat) partials
+__global__ __launch_bounds__(256) void bn_tiles_stage1_kernel(const PT* __restrict__ partial, int tiles, int C,
                                                                double* __restrict__ scratch) {
   __shared__ double red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -239,11 +273,12 @@ extern "C" int mla_bn_finalize(const float* partial, int tiles, int M, int C, fl
   MLA_REQUIRE(partial && mean && invstd && tiles > 0 && M > 0 && C > 0, "mla_bn_finalize: bad argument");
   MLA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mla_bn_finalize: running stats must come in pairs");
   MLA_REQUIRE(((uintptr_t)partial % 8) == 0, "mla_bn_finalize: partial must be 8-byte aligned");
-  // scratch tail: right after the tiles (tiles*2*C floats is a multiple of 2 floats -> 8-byte aligned)
+  // scratch tail: right after the tiles
   hipStream_t st = (hipStream_t)stream;
-  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (size_t)tiles * 2 * C);
+  const double* pd = reinterpret_cast<const double*>(partial);                     // fp64 [tiles][2][C] (conv epilogue / bn_stats_partial)
+  double* scratch = const_cast<double*>(pd) + (size_t)tiles * 2 * C;
   const int S = bn_red_chunks(tiles);
-  bn_tiles_stage1_kernel<<<dim3(cdiv(C, 64), S), 256, 0, st>>>(partial, tiles, C, scratch);
+  bn_tiles_stage1_kernel<double><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(pd, tiles, C, scratch);
   MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
   bn_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, M, C, eps, momentum, mean, invstd, running_mean, running_var);
   MLA_CHECK_LAUNCH("bn_finalize_kernel");
@@ -271,7 +306,7 @@ extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float*
   MLA_CHECK_LAUNCH("bn_reduce_kernel<1>");
   double* scratch = reinterpret_cast<double*>(ws + (size_t)nt * 2 * C);
   const int S = bn_red_chunks(nt);
-  bn_tiles_stage1_kernel<<<dim3(cdiv(C, 64), S), 256, 0, st>>>(ws, nt, C, scratch);
+  bn_tiles_stage1_kernel<float><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(ws, nt, C, scratch);
   MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
   bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
   MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");

@@ -439,7 +439,7 @@ static int fwd_cfg(long M, int Cin, int Cout) {
 
 extern "C" size_t mla_conv2d_fwd_partial_elems(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
   const long M = (long)N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad);
-  return (size_t)cdiv(M, 64) * 2 * Cout + mla_bn_partial_scratch_elems(Cout);  // upper bound over the tile choices + reduce scratch
+  return (size_t)cdiv(M, 64) * 2 * Cout * 2 + mla_bn_partial_scratch_elems(Cout);  // fp64 partials (2 floats each), upper bound over the tile choices, + reduce scratch
 }
 
 extern "C" int mla_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int KH,

@@ -66,9 +66,12 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / 
   const int wm = wave / WN, wn = wave % WN;
   const int gCO = g.CO;
   const int h = lane >> 5, j = lane & 31;
-  float csum[NI], csq[NI];
+  // BatchNorm statistics of the tile are accumulated in fp64: v * v is exact there (24 x 24 significand bits) and the later
+  // E[x^2] - E[x]^2 then cancels against ~1e-16 instead of the ~1e-7 of fp32 tile sums, so channels with |mean| >> std keep
+  // their variance (ATen uses Welford; tests/test_ops_gpu.py::test_bn_large_mean).  Only instantiated work when part != null.
+  double csum[NI], csq[NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) csum[ni] = csq[ni] = 0.f;
+  for (int ni = 0; ni < NI; ++ni) csum[ni] = csq[ni] = 0.0;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     size_t off[16];
@@ -124,32 +127,37 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / 
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const float v = acc[mi][ni][e];
-        csum[ni] += v;          // rows past M hold exact zeros (zero A rows), so no masking is needed;
-        csq[ni] += v * v;       // the statistics are only requested by the forward conv (no R / MASK)
+        if (part) {             // rows past M hold exact zeros (zero A rows), so no masking is needed;
+          const double vd = (double)v;   // the statistics are only requested by the forward conv (no R / MASK)
+          csum[ni] += vd;
+          csq[ni] += vd * vd;
+        }
         if (ok[e]) Y[off[e] + ni * 32] = v;
       }
   }
-  if (part) {  // fused BatchNorm statistics: per-tile column sum / sum of squares
+  if (part) {  // fused BatchNorm statistics: per-tile column sum / sum of squares, fp64 [tiles][2][C]
+    double* redd = reinterpret_cast<double*>(red);           // WM * 2 * BN doubles <= 8 KB of the (free) operand LDS
+    double* partd = reinterpret_cast<double*>(part);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       csum[ni] += __shfl_xor(csum[ni], 32, 64);
       csq[ni] += __shfl_xor(csq[ni], 32, 64);
       if (h == 0) {
         const int c = wn * (BN / WN) + ni * 32 + j;
-        red[(wm * 2 + 0) * BN + c] = csum[ni];
-        red[(wm * 2 + 1) * BN + c] = csq[ni];
+        redd[(wm * 2 + 0) * BN + c] = csum[ni];
+        redd[(wm * 2 + 1) * BN + c] = csq[ni];
       }
     }
     __syncthreads();
     if (tid < BN) {
-      float s = 0.f, q = 0.f;
+      double s = 0.0, q = 0.0;
 #pragma unroll
       for (int w = 0; w < WM; ++w) {
-        s += red[(w * 2 + 0) * BN + tid];
-        q += red[(w * 2 + 1) * BN + tid];
+        s += redd[(w * 2 + 0) * BN + tid];
+        q += redd[(w * 2 + 1) * BN + tid];
       }
-      part[((size_t)tm * 2 + 0) * gCO + tn * BN + tid] = s;
-      part[((size_t)tm * 2 + 1) * gCO + tn * BN + tid] = q;
+      partd[((size_t)tm * 2 + 0) * gCO + tn * BN + tid] = s;
+      partd[((size_t)tm * 2 + 1) * gCO + tn * BN + tid] = q;
     }
   }
 }

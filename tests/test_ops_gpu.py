@@ -71,7 +71,7 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, k, k, s, p), device="cuda")
     y, tiles = ops.conv2d_fwd(xd, wd, s, p, bn_partial=part)
     assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="conv fwd")
-    pt = part[:tiles * 2 * Cout].view(tiles, 2, Cout).double().sum(0).cpu()    # buffer is an upper-bound allocation
+    pt = part.view(torch.float64)[:tiles * 2 * Cout].view(tiles, 2, Cout).sum(0).cpu()    # fp64 partials; upper-bound allocation
     assert_close(pt[0], y_ref.double().sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="fused colsum")
     assert_close(pt[1], (y_ref.double() ** 2).sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="fused colsumsq")
 
@@ -119,7 +119,7 @@ def test_conv_split_fwd_dgrad(ops, case, cfg):
         part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, k, k, s, p), device="cuda")
         y, tiles = ops.conv2d_fwd_split(xd, w_t, wd.shape, s, p, bn_partial=part)
         assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="split conv fwd")
-        pt = part[:tiles * 2 * Cout].view(tiles, 2, Cout).double().sum(0).cpu()
+        pt = part.view(torch.float64)[:tiles * 2 * Cout].view(tiles, 2, Cout).sum(0).cpu()      # fp64 partials
         assert_close(pt[0], y_ref.double().sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="split fused colsum")
         assert_close(pt[1], (y_ref.double() ** 2).sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="split fused colsumsq")
         dx_ref = O.conv2d_dgrad(dy, w, x.shape, s, p)
@@ -199,7 +199,7 @@ def test_conv_f32_every_tile(ops, cfg):
         part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, k, k, s, p), device="cuda")
         y, tiles = ops.conv2d_fwd(xd, wd, s, p, bn_partial=part)
         assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="conv fwd")
-        pt = part[:tiles * 2 * Cout].view(tiles, 2, Cout).double().sum(0).cpu()
+        pt = part.view(torch.float64)[:tiles * 2 * Cout].view(tiles, 2, Cout).sum(0).cpu()      # fp64 partials
         assert_close(pt[0], y_ref.double().sum(dim=(0, 2, 3)), atol=1e-3, rtol=2e-5, name="fused colsum")
         dx = ops.conv2d_dgrad(dyd, wd, (N, H, W, Cin), s, p, torch.empty(w.numel(), device="cuda"))
         assert_close(nchw(dx.cpu()), O.conv2d_dgrad(dy, w, x.shape, s, p), atol=0, rtol=2e-5, name="conv dgrad")
@@ -262,6 +262,49 @@ def test_bn_fwd_bwd(ops, M, C):
     ops.bn_bwd(d2, xd, mean, invstd, gamma.cuda(), d2, dgamma, dbeta, ws, M, C)
     dx_ref2, _, _ = O.bn_train_bwd(dout, x, gamma, mean_ref, invstd_ref)
     assert_close(d2.cpu(), nhwc(dx_ref2).view(M, C), atol=1e-6, rtol=2e-5, name="bn dx in place")
+
+
+@pytest.mark.parametrize("ratio", [50.0, 2000.0])
+def test_bn_large_mean(ops, ratio):
+    """the batch variance is formed as E[x^2] - E[x]^2, which cancels catastrophically in fp32 when
+    |mean| >> std (ATen uses Welford).  The per-tile sums are therefore fp64 (x * x is exact in fp64), in the conv epilogue
+    and in the standalone statistics kernel alike.  Channels with mean / std = 50 and 2000: mean, invstd, running_var and the
+    normalised output against an fp64 evaluation."""
+    M, C = 20000, 64
+    g = torch.Generator().manual_seed(int(ratio))
+    z = torch.randn((M, C), generator=g, dtype=torch.float64)
+    x64 = (z * 0.37 + 0.37 * ratio * torch.linspace(-1.0, 1.0, C, dtype=torch.float64).sign())          # every channel: |mean| / std = ratio
+    x = x64.float()
+    xd = x.cuda()
+    m_ref, v_ref = x.double().mean(0), x.double().var(0, unbiased=False)
+    part = torch.empty(ops.bn_stats_partial_elems(M, C), device="cuda")
+    tiles = ops.bn_stats_partial(xd, M, C, part)
+    mean, invstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    ops.bn_finalize(part, tiles, M, C, mean, invstd, rm, rv)
+    assert_close(mean, m_ref, atol=0, rtol=2e-7, name="mean")
+    assert_close(invstd, 1.0 / torch.sqrt(v_ref + 1e-5), atol=0, rtol=1e-6, name="invstd (standalone statistics)")
+    assert_close(rv, 0.9 + 0.1 * v_ref * M / (M - 1), atol=0, rtol=1e-6, name="running_var")
+    out = torch.empty((M, C), device="cuda")
+    ones, zeros = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.bn_apply(xd, mean, invstd, ones, zeros, out, M, C, False)
+    ref = (x.double() - m_ref) / torch.sqrt(v_ref + 1e-5)
+    # the subtraction x - mean is exact-ish in fp32 only to ulp(x) = ratio * 6e-8 relative to std: that floor is inherent to fp32 data
+    assert_close(out, ref, atol=4e-7 * ratio + 2e-6, rtol=0, name="normalised output")
+    # the same statistics out of the conv epilogue: a 1x1 convolution with identity weights reproduces x as its output
+    if ratio <= 50:
+        xin = x.view(100, 200, 1, C).contiguous().cuda()
+        w = torch.eye(C, device="cuda").view(1, 1, C, C).contiguous()
+        for conv in ("f32", "split"):
+            part2 = torch.empty(ops.conv2d_fwd_partial_elems(100, 200, 1, C, C, 1, 1, 1, 0), device="cuda")
+            if conv == "f32":
+                y, t2 = ops.conv2d_fwd(xin, w, 1, 0, bn_partial=part2)
+            else:
+                y, t2 = ops.conv2d_fwd_split(xin, ops.conv2d_wsplit(w, True), w.shape, 1, 0, bn_partial=part2)
+            assert torch.equal(y.view(M, C), xd), "identity 1x1 convolution"
+            ops.bn_finalize(part2, t2, M, C, mean, invstd, None, None)
+            assert_close(mean, m_ref, atol=0, rtol=2e-7, name=f"mean (conv epilogue, {conv})")
+            assert_close(invstd, 1.0 / torch.sqrt(v_ref + 1e-5), atol=0, rtol=1e-6, name=f"invstd (conv epilogue, {conv})")
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 16, 12, 64), (3, 9, 7, 64), (1, 2, 2, 128)])
