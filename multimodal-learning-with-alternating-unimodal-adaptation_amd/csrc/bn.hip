@@ -15,7 +15,9 @@
 static size_t bn_red_scratch_floats(int C);
 // ---- tiling shared by the stats and backward-reduce kernels --------------------------------
 static int bn_tile_rows(int M) {
-  long t = ((long)M + 2047) / 2048;  // aim at ~2048 workgroups
+  // aim at ~2048 workgroups for the big activations (stem, layer1: > 256 K rows), ~1024 below (then the statistics are
+  // finalized by ONE launch, bn_finalize_tiles_kernel)
+  long t = M > (1 << 18) ? ((long)M + 2047) / 2048 : ((long)M + 1023) / 1024;
   t = ((t + 15) / 16) * 16;
   if (t < 32) t = 32;
   if (t > 1024) t = 1024;
@@ -204,6 +206,59 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   dgamma[c] = (float)q;
 }
 
+// One-launch finalize for tile counts <= BN_ONE_MAXT (every layer but the stem and layer1 forward): a block owns 16
+// channels x 16 tile lanes; lane k sums tiles k, k+16, ... (four loads in flight), the 16 lanes are combined through LDS
+// in a fixed order, then the statistics are formed exactly as in bn_finalize_kernel / bn_bwd_finalize_kernel.  Replaces
+// the stage-1 + finalize pair (two dependent 5-8 us launches on the serial conv -> statistics -> apply chain) by one.
+#define BN_ONE_MAXT 1024
+template <typename PT, int FWD>
+__global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const PT* __restrict__ partial, int tiles, int M, int C, float eps,
+                                                                 float momentum, float* __restrict__ out0, float* __restrict__ out1,
+                                                                 float* running_mean, float* running_var) {
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    int t = kl;
+    for (; t + 48 < tiles; t += 64) {
+      const double a0 = (double)partial[((size_t)t * 2 + 0) * C + c], b0 = (double)partial[((size_t)t * 2 + 1) * C + c];
+      const double a1 = (double)partial[((size_t)(t + 16) * 2 + 0) * C + c], b1 = (double)partial[((size_t)(t + 16) * 2 + 1) * C + c];
+      const double a2 = (double)partial[((size_t)(t + 32) * 2 + 0) * C + c], b2 = (double)partial[((size_t)(t + 32) * 2 + 1) * C + c];
+      const double a3 = (double)partial[((size_t)(t + 48) * 2 + 0) * C + c], b3 = (double)partial[((size_t)(t + 48) * 2 + 1) * C + c];
+      s += (a0 + a1) + (a2 + a3);
+      q += (b0 + b1) + (b2 + b3);
+    }
+    for (; t < tiles; t += 16) {
+      s += (double)partial[((size_t)t * 2 + 0) * C + c];
+      q += (double)partial[((size_t)t * 2 + 1) * C + c];
+    }
+  }
+  red[0][kl][cl] = s;
+  red[1][kl][cl] = q;
+  __syncthreads();
+  if (kl != 0 || c >= C) return;
+  for (int k = 1; k < 16; ++k) {
+    s += red[0][k][cl];
+    q += red[1][k][cl];
+  }
+  if (FWD) {
+    const double m = s / M;
+    double var = q / M - m * m;
+    if (var < 0.0) var = 0.0;
+    out0[c] = (float)m;                                           // mean
+    out1[c] = (float)(1.0 / sqrt(var + (double)eps));             // invstd
+    if (running_mean) {
+      const double unb = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  } else {
+    out1[c] = (float)s;                                           // dbeta
+    out0[c] = (float)q;                                           // dgamma
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -276,6 +331,11 @@ extern "C" int mla_bn_finalize(const float* partial, int tiles, int M, int C, fl
   // scratch tail: right after the tiles
   hipStream_t st = (hipStream_t)stream;
   const double* pd = reinterpret_cast<const double*>(partial);                     // fp64 [tiles][2][C] (conv epilogue / bn_stats_partial)
+  if (tiles <= BN_ONE_MAXT) {
+    bn_finalize_tiles_kernel<double, 1><<<cdiv(C, 16), 256, 0, st>>>(pd, tiles, M, C, eps, momentum, mean, invstd, running_mean, running_var);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+    return MLA_OK;
+  }
   double* scratch = const_cast<double*>(pd) + (size_t)tiles * 2 * C;
   const int S = bn_red_chunks(tiles);
   bn_tiles_stage1_kernel<double><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(pd, tiles, C, scratch);
@@ -304,12 +364,17 @@ extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float*
   const int tr = bn_tile_rows(M), nt = cdiv(M, tr);
   bn_reduce_kernel<1><<<nt, 256, 0, st>>>(x, dout, relu_out, mean, invstd, ws, M, C, tr);
   MLA_CHECK_LAUNCH("bn_reduce_kernel<1>");
-  double* scratch = reinterpret_cast<double*>(ws + (size_t)nt * 2 * C);
-  const int S = bn_red_chunks(nt);
-  bn_tiles_stage1_kernel<float><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(ws, nt, C, scratch);
-  MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
-  bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
-  MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  if (nt <= BN_ONE_MAXT) {
+    bn_finalize_tiles_kernel<float, 0><<<cdiv(C, 16), 256, 0, st>>>(ws, nt, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+  } else {
+    double* scratch = reinterpret_cast<double*>(ws + (size_t)nt * 2 * C);
+    const int S = bn_red_chunks(nt);
+    bn_tiles_stage1_kernel<float><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(ws, nt, C, scratch);
+    MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
+    bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
+    MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  }
   const size_t n4 = (size_t)M * C / 4;
   bn_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(dout, relu_out, x, mean, invstd, gamma, dgamma, dbeta, dx, g_out, n4,
                                                    C / 4, 1.0f / (float)M);
