@@ -268,6 +268,34 @@ def test_rccl_path_single_rank_matches_local():
         assert torch.equal(model_d.visual_net.flat.cpu(), model_l.visual_net.flat.cpu())
         assert torch.equal(model_d.fusion_module.fc_out.flat.cpu(), model_l.fusion_module.fc_out.flat.cpu())
         assert torch.equal(tr_d.gs_plugin.Pl.cpu(), tr_l.gs_plugin.Pl.cpu())
+        # Critical-path cost of the packed head exchange: HIP events on the calling stream around
+        # Comm.exchange_head (pack -> all-reduce on the head communicator -> unpack), and the 44.7 MB encoder-gradient
+        # all-reduce beside it.  One RCCL rank: the software floor (launches + RCCL kernel), no xGMI wire time.
+        import json
+        comm, head = tr_d.comm, model_d.fusion_module.fc_out
+        colsum, loss, msg = tr_d._colsum, tr_d.losses["loss_a"], tr_d._msg
+
+        def timed(fn, n=50):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(n):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e) / n * 1e3
+        us_head = timed(lambda: comm.exchange_head(head.grad, colsum, loss, msg))
+        us_enc = timed(lambda: comm.wait(comm.allreduce_flat_async(model_d.audio_net.grad)), n=10)
+        rep = {"rccl_ranks": 1, "head_exchange_us": round(us_head, 1), "head_message_floats": int(msg.numel()),
+               "encoder_grad_allreduce_us": round(us_enc, 1), "encoder_grad_bytes": int(model_d.audio_net.grad.numel() * 4),
+               "bucket_bytes": 8 << 20,
+               "note": "single RCCL rank on one MI355X: launch + kernel floor of the two collectives; no multi-GPU box was available"}
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "reports")
+        os.makedirs(d, exist_ok=True)
+        json.dump(rep, open(os.path.join(d, "head_exchange_rccl_1rank.json"), "w"), indent=1)
+        assert us_head < 5000
     finally:
         dist.destroy_process_group()
 
