@@ -377,3 +377,101 @@ def test_torch_library_ops(golden_dir):
     assert_close(pp, p0 - 1e-2 * (g + 1e-4 * p0), atol=1e-7, rtol=1e-6, name="sgd first step")
     with pytest.raises((NotImplementedError, RuntimeError)):
         T.sgd_step(pp.cpu(), g.cpu(), buf.cpu(), 1e-2, 0.9, 1e-4, True)        # no CPU kernel: loud
+
+
+@pytest.mark.parametrize("which", ["m3ae", "modal3"])
+def test_reference_loop_verbatim_transformer_classifiers(which):
+    """main.py:419-476 with --lorb m3ae (and --modal3): `a, v = model(token, padding_mask, image)` resp.
+    `a, v, t = model(token, padding_mask, image, spec)`, then the per-modality blocks incl. the third one (main.py:455-466),
+    executed verbatim on M3AEClassifier / Modal3Classifier protocol objects -- against the fused MLATrainer on an identical
+    model (same launch plans): features / losses / raw head gradients to 1e-5, the updated head and every encoder to 1e-6."""
+    import mla_hip
+    from test_dist_gpu import T_B, _build_transformer, _transformer_case
+
+    class args:
+        lorb, modal3, clip = "m3ae", which == "modal3", False
+    A, sd, inputs, label = _transformer_case(which)
+    model_t, tr, _i, _l = _build_transformer(which)
+    tr.set_overlap(False)
+    cls = mla_hip.M3AEClassifier if which == "m3ae" else mla_hip.Modal3Classifier
+    from test_dist_gpu import T_DEPTH, T_VOCAB
+    model = cls(A(), depth=T_DEPTH, text_vocab_size=T_VOCAB, seed=0)
+    model.load_state_dict(sd)
+    model = mla_hip.DataParallel(model, device_ids=[0])
+    optimizer = mla_hip.FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    gs_plugin = mla_hip.GSPlugin()                       # eye(512) by default; takes D = 768 from the head it is handed (Q3)
+    criterion = mla_hip.CrossEntropyLoss()
+    dev = [x.cuda() for x in inputs]
+    label = label.cuda()
+    if which == "m3ae":
+        token, padding_mask, image = dev
+    else:
+        token, padding_mask, image, spec = dev
+    model.train()
+    for batch_step in range(2):
+        len_dataloader = 10
+        optimizer.zero_grad()
+        # ---- main.py:419-466, verbatim
+        if args.lorb == "large":
+            a, v = model(spec, image)
+        elif args.lorb == "m3ae":
+            if args.modal3:
+                a, v, t = model(token, padding_mask, image, spec)
+            else:
+                a, v = model(token, padding_mask, image)
+        out_a = model.module.fusion_module.fc_out(a)
+
+        loss_a = criterion(out_a, label)
+        loss_a.backward()
+
+        gs_plugin.before_update(model.module.fusion_module.fc_out, a,
+                                batch_step, len_dataloader, gs_plugin.exp_count)
+        optimizer.step()
+        optimizer.zero_grad()
+
+        gs_plugin.exp_count += 1
+
+        out_v = model.module.fusion_module.fc_out(v)
+
+        loss_v = criterion(out_v, label)
+        loss_v.backward()
+
+        gs_plugin.before_update(model.module.fusion_module.fc_out, v,
+                                batch_step, len_dataloader, gs_plugin.exp_count)
+        optimizer.step()
+        optimizer.zero_grad()
+
+        gs_plugin.exp_count += 1
+        if args.modal3:
+            out_t = model.module.fusion_module.fc_out(t)
+
+            loss_t = criterion(out_t, label)
+            loss_t.backward()
+
+            gs_plugin.before_update(model.module.fusion_module.fc_out, t,
+                                    batch_step, len_dataloader, gs_plugin.exp_count)
+            optimizer.step()
+            optimizer.zero_grad()
+
+            gs_plugin.exp_count += 1
+
+        for n, p in model.named_parameters():
+            if p.grad != None:
+                del p.grad
+        # ---- the fused trainer on the twin model
+        losses = tr.train_step(*dev, label, batch_step, len_dataloader)
+        torch.cuda.synchronize()
+        assert_close(a, tr.last["a"], atol=1e-5, name=f"step {batch_step} feature a")
+        assert_close(v, tr.last["v"], atol=1e-5, name=f"step {batch_step} feature v")
+        assert abs(loss_a.item() - losses["loss_a"].item()) < 1e-5 and abs(loss_v.item() - losses["loss_v"].item()) < 1e-5
+        if args.modal3:
+            assert_close(t, tr.last["t"], atol=1e-5, name="feature t")
+            assert abs(loss_t.item() - losses["loss_t"].item()) < 1e-5
+    assert gs_plugin.exp_count == tr.gs_plugin.exp_count == (6 if args.modal3 else 4) and gs_plugin.Pl.shape == (768, 768)
+    # the projection of this path is ill-conditioned on transformer features (DESIGN section 8): compare what feeds it and the
+    # encoders tightly, the projected quantities loosely
+    for (tag, _g, enc_t), enc_p in zip(model_t.mla_encoders(), [e for _t, _g2, e in model.module.mla_encoders()]):
+        assert_close(enc_p.flat, enc_t.flat, atol=2e-6, name=f"encoder {tag} parameters after 2 steps")
+    assert_close(model.module.fusion_module.fc_out.flat, model_t.fusion_module.fc_out.flat, atol=5e-5, name="head after 2 steps")
+    names = [n for n, _p in model.module.named_parameters()]
+    assert names[0] == "fusion_module.fc_out.weight" and any(n.startswith("mae_v.encoder.blocks.1.attention.qkv_linear") for n in names)
