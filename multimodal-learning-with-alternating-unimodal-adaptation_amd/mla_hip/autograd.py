@@ -14,9 +14,10 @@ Graph recording is triggered by a private 1-element `anchor` tensor (requires_gr
 the flat-buffer views as `.grad` itself, with autograd's accumulate rule (module.py).  Under `torch.no_grad()`
 (evaluation, main.py:520) nothing is recorded and only the forward kernels run.
 
-Data parallel (mla_hip.DataParallel, one process per GPU): d logits are pre-scaled by 1/world so every local gradient
-is a share of the global-batch mean; HeadLinear.backward all-reduces the packed (dW|db) before it is published, the
-encoder gradient all-reduce is issued asynchronously on RCCL's stream and waited for by FusedSGD.step().
+Data parallel (mla_hip.DataParallel, one process per GPU): HeadLinear.backward scales dW, db and dX by 1/world (the criterion
+averaged over the LOCAL batch), so every local gradient -- the encoder's included, through dX -- is a share of the
+global-batch mean; it all-reduces the packed (dW|db) before it is published; the encoder gradient all-reduce (SUM) is issued
+asynchronously on RCCL's stream and waited for by FusedSGD.step().
 """
 from __future__ import annotations
 
@@ -44,10 +45,8 @@ class EncoderFeature(torch.autograd.Function):
         if enc._fwd_token is not ctx.token:
             raise RuntimeError("mla_hip: backward through a stale encoder forward (the activation workspace holds the "
                                "most recent forward only; retain_graph / double backward are not supported)")
-        comm = enc.comm
-        if comm is not None and comm.active:
-            dfeat = dfeat * (1.0 / comm.world)
-        pending = enc.grads_pending()
+        comm = enc.comm        # data parallel: d feature already is this rank's share of the global-batch mean (HeadLinear.backward
+        pending = enc.grads_pending()          # scales by 1 / world), so the flat encoder gradient only needs the SUM over ranks
         enc.backward_from_pooled(dfeat.contiguous(), enc._pa)
         if comm is not None and comm.active:
             enc._grad_works = comm.allreduce_flat_async(enc.grad)      # waited for by FusedSGD.step()

@@ -246,3 +246,91 @@ def test_two_rank_dynamic_eval_equals_single_process_global_batch(tmp_path):
         assert torch.equal(r["counts"], ev.counts.cpu())
         assert_close(r["weights"], ev.weights, atol=1e-6, name="global-batch entropy weights")
     assert int(r0["counts"][:6].sum()) == spec.shape[0]                       # every rank counted the whole batch
+
+
+# ---- the PROTOCOL path under data parallel: mla_hip.DataParallel + autograd Functions + FusedSGD + GSPlugin ---------------------
+def _protocol_steps(model, optimizer, gs_plugin, criterion, inputs, label, steps=2):
+    """main.py:426-454, 468-470 (two modalities, --lorb m3ae) for `steps` batches; returns the last losses."""
+    token, padding_mask, image = inputs
+    out = None
+    for batch_step in range(steps):
+        optimizer.zero_grad()
+        a, v = model(token, padding_mask, image)
+        out_a = model.module.fusion_module.fc_out(a)
+        loss_a = criterion(out_a, label)
+        loss_a.backward()
+        gs_plugin.before_update(model.module.fusion_module.fc_out, a, batch_step, 10, gs_plugin.exp_count)
+        optimizer.step()
+        optimizer.zero_grad()
+        gs_plugin.exp_count += 1
+        out_v = model.module.fusion_module.fc_out(v)
+        loss_v = criterion(out_v, label)
+        loss_v.backward()
+        gs_plugin.before_update(model.module.fusion_module.fc_out, v, batch_step, 10, gs_plugin.exp_count)
+        optimizer.step()
+        optimizer.zero_grad()
+        gs_plugin.exp_count += 1
+        for n, p in model.named_parameters():
+            if p.grad != None:
+                del p.grad
+        out = (loss_a.detach().clone(), loss_v.detach().clone())
+    return out
+
+
+def _build_protocol_m3ae(comm=None):
+    import mla_hip
+    A, sd, inputs, label = _transformer_case("m3ae")
+    model = mla_hip.M3AEClassifier(A(), depth=T_DEPTH, text_vocab_size=T_VOCAB, seed=0)
+    model.load_state_dict(sd)
+    model = mla_hip.DataParallel(model, comm=comm)
+    optimizer = mla_hip.FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    return model, optimizer, mla_hip.GSPlugin(mode="as_published"), mla_hip.CrossEntropyLoss(), inputs, label
+
+
+def _worker_protocol(rank, port, outdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    from mla_hip import Comm
+    model, optimizer, gs, crit, inputs, label = _build_protocol_m3ae(Comm(bucket_bytes=4 << 20))
+    per = T_B // WORLD
+    sl = slice(rank * per, (rank + 1) * per)
+    model.train()
+    la, lv = _protocol_steps(model, optimizer, gs, crit, [x[sl].cuda() for x in inputs], label[sl].cuda())
+    torch.cuda.synchronize()
+    m = model.module
+    torch.save({"head": m.fusion_module.fc_out.flat.cpu(), "text": m.mae_a.flat.cpu(), "image": m.mae_v.flat.cpu(),
+                "loss": torch.stack([la, lv]).cpu()}, os.path.join(outdir, f"proto{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_protocol_path_equals_global_batch(tmp_path):
+    """mla_hip.DataParallel on the object protocol: d logits pre-scaled by 1/world and the packed dW|db all-reduced in
+    HeadLinear.backward, the flat encoder gradient all-reduced asynchronously in EncoderFeature.backward and awaited by
+    FusedSGD.step().  Two ranks (two steps, momentum included) must end with the parameters of ONE process that runs the
+    same loop on the whole batch (transformer encoders: no per-rank statistics); the mean of the ranks' local losses is the
+    global loss.  Projection off (as_published): its conditioning on transformer features is tested elsewhere."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_protocol, args=(r, port, str(tmp_path))) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    r0 = torch.load(tmp_path / "proto0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "proto1.pt", weights_only=True)
+    model, optimizer, gs, crit, inputs, label = _build_protocol_m3ae()
+    model.train()
+    la, lv = _protocol_steps(model, optimizer, gs, crit, [x.cuda() for x in inputs], label.cuda())
+    torch.cuda.synchronize()
+    m = model.module
+    for k in ("head", "text", "image"):
+        assert torch.equal(r0[k], r1[k]), f"ranks must hold identical {k} parameters"
+    assert_close(r0["head"], m.fusion_module.fc_out.flat, atol=1e-6, name="head after 2 data-parallel steps")
+    assert_close(r0["image"], m.mae_v.flat, atol=1e-6, name="image encoder after 2 data-parallel steps")
+    assert_close(r0["text"], m.mae_a.flat, atol=1e-6, name="text encoder after 2 data-parallel steps")
+    assert_close((r0["loss"] + r1["loss"]) / 2, torch.stack([la, lv]), atol=1e-5, name="mean of rank losses = global loss")

@@ -320,6 +320,20 @@ def test_gradient_accumulation_and_foreign_gradients():
     optimizer.step()
     got = before - p.detach()                                # first step: buf = g + wd*p; p -= lr*buf
     assert_close(got, 1e-3 * (want_g + 1e-4 * before), atol=1e-7, rtol=1e-4, name="foreign gradient honoured")
+    # partially-None owner: torch.optim.SGD skips exactly the parameters whose .grad is None (per-segment launches here),
+    # and their momentum buffers stay where they were
+    one_backward()
+    params = dict(enc.named_parameters())
+    skip, keep = params["layer2.0.conv1.weight"], params["layer2.0.conv2.weight"]
+    skip.grad = None
+    w_skip, w_keep, g_keep = skip.detach().clone(), keep.detach().clone(), keep.grad.clone()
+    mom_keep = optimizer._mom_view([k for k, o in optimizer.groups.items() if o is enc][0], keep._mla_index).clone()
+    optimizer.step()
+    assert torch.equal(skip.detach(), w_skip), "a parameter without gradient must not move"
+    buf = 0.9 * mom_keep + (g_keep + 1e-4 * w_keep)                    # second step of this parameter: momentum applies
+    assert_close(w_keep - keep.detach(), 1e-3 * buf, atol=1e-8, rtol=1e-4, name="per-segment step")
+    sd = optimizer.state_dict()
+    assert len(sd["state"]) == 122 - 60                                     # head + audio encoder stepped; the visual encoder never did
 
 
 def test_torch_library_ops(golden_dir):
