@@ -207,7 +207,9 @@ def _dump_report(name, obj):
         json.dump(obj, f, indent=1)
 
 
-PROJ_TOL_STEP0 = 1.5e-3   # measured 1.00e-3 (f32) / 1.24e-3 (split) against the fixture, 4.0e-4 / 3.0e-4 against fp64: profiles/r02_m3ae_projection_errors_*.json
+PROJ_TOL_STEP0 = 3e-3     # measured 1.0e-3 ... 1.5e-3 (f32) / 1.2e-3 (split) against the fixture depending on last-bit differences of the
+                          # features (a 1e-6 relative feature perturbation moves this quantity by 1.7e-3), 3e-4 ... 4e-4 against fp64:
+                          # profiles/r02_m3ae_projection_errors_*.json
 
 
 def test_assemble_patchify_avgpool(ops):
