@@ -188,7 +188,7 @@ __device__ __forceinline__ float vec_wsum(const float* __restrict__ tile, float 
 // forward: workgroup = 128 queries of one (b, h); loop over key tiles of 32.  o (B, n, H*64), lse (B, H, n).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int W, int TAIL>
-__global__ __launch_bounds__(64 * W, 3) void attn_fwd_kernel(const AttGeom g, float* __restrict__ O, float* __restrict__ LSE) {
+__global__ __launch_bounds__(64 * W, W >= 3 ? 3 : 2) void attn_fwd_kernel(const AttGeom g, float* __restrict__ O, float* __restrict__ LSE) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 32 * ATT_LD + 2 * 32];
   float* Ks = smem;                       // [2][32][ATT_LD]
   float* Vs = smem + 2 * 32 * ATT_LD;     // [2][32][ATT_LD]
