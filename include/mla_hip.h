@@ -116,6 +116,16 @@ int mla_bn_bwd(const float* dout, const float* relu_out, const float* x, const f
                const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                float* g_out, float* ws, int M, int C, void* stream);
 
+/* Stem conv1 -> bn1 -> relu -> maxpool (backbone.py:149-152) without materialising the ReLU output: the max-pool applies
+ * BN + ReLU to y (NHWC conv output) on the fly; out (N,OH,OW,C), idx = window position 0..8 of the first maximum. */
+int mla_bn_relu_maxpool_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, float* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
+/* ... and its backward: BatchNorm backward whose upstream gradient is gathered from the POOLED gradient dpool (N,OH,OW,C)
+ * through idx and masked by bn(y) > 0; dy (N,H,W,C) = gradient w.r.t. y, dgamma / dbeta written; ws >= mla_bn_bwd_ws_elems. */
+int mla_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const float* y, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta, float* ws,
+                      int N, int H, int W, int C, void* stream);
+
 /* ---- pooling ---------------------------------------------------------------------------------- */
 /* nn.MaxPool2d(3,2,1) (backbone.py:88,152); idx = window position 0..8 of the first maximum. */
 int mla_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);

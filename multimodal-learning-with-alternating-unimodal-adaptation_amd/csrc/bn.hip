@@ -259,6 +259,14 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const PT* __rest
   }
 }
 
+// the one BN expression (explicit fma) every kernel that forms or re-forms bn(x) uses: identical rounding everywhere
+__device__ __forceinline__ f32x4 bn_val(const f32x4 x, const f32x4 mu, const f32x4 is, const f32x4 ga, const f32x4 be) {
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = fmaf((x[e] - mu[e]) * is[e], ga[e], be[e]);
+  return r;
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int cg = (int)(idx % c4n);
     const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
     const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
-    f32x4 v = (reinterpret_cast<const f32x4*>(x)[idx] - mu) * is * ga + be;
+    f32x4 v = bn_val(reinterpret_cast<const f32x4*>(x)[idx], mu, is, ga, be);
     if (residual) v += reinterpret_cast<const f32x4*>(residual)[idx];
     if (relu) {
 #pragma unroll
@@ -299,6 +307,136 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
     const f32x4 xhat = (reinterpret_cast<const f32x4*>(x)[idx] - mu) * is;
     if (g_out) reinterpret_cast<f32x4*>(g_out)[idx] = g;
     reinterpret_cast<f32x4*>(dx)[idx] = ga * is * (g - db - xhat * dg);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem: conv1 -> bn1 -> relu -> maxpool(3, 2, 1) (backbone.py:149-152).  The stem activations are the largest tensors of the
+// network (N x 112 x 112 x 64 resp. N x 512 x 64 x 64: 1.15 GB per pass at batch 64), and everything around them is
+// HBM-bound, so the ReLU output is never materialised:
+//   forward   mla_bn_relu_maxpool_fwd: the max-pool reads y (the conv output) and applies BN + ReLU on the fly
+//             (saves writing and re-reading a_stem: 2.3 GB per step);
+//   backward  mla_bn_bwd_pooled: the BatchNorm backward takes its upstream gradient straight from the POOLED gradient --
+//             g[pixel] = [bn(y) > 0] * sum over the <= 4 windows that selected this pixel -- in both its reduction and its
+//             apply pass (saves writing and twice re-reading the scattered gradient and reading a_stem: 4.2 GB per step).
+// bn_val (above) is the one expression both directions use, so the recomputed ReLU mask and the max-pool decisions agree
+// bit for bit.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// idx = kh*3+kw of the FIRST maximum in row-major window order (ATen: `val > maxval || isnan(val)`), as maxpool_fwd_kernel
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ out,
+                                                                   uint8_t* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
+  const int c4n = C >> 2;
+  const size_t total = (size_t)N * OH * OW * c4n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % c4n);
+    size_t p = i / c4n;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int n = (int)(p / OH);
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy * 2 - 1 + kh;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = ox * 2 - 1 + kw;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        f32x4 v = bn_val(reinterpret_cast<const f32x4*>(y)[((size_t)(n * H + iy) * W + ix) * c4n + cg], mu, is, ga, be);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = v[e] != v[e] ? v[e] : fmaxf(v[e], 0.f);          // relu, NaN kept
+          if (first || v[e] > best[e] || v[e] != v[e]) {
+            best[e] = v[e];
+            bi[e] = kh * 3 + kw;
+          }
+        }
+        first = false;
+      }
+    }
+    reinterpret_cast<f32x4*>(out)[i] = best;
+    reinterpret_cast<uchar4*>(idx)[i] = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+  }
+}
+
+// upstream gradient of stem pixel (n, iy, ix), channel group cg, before the ReLU mask: gather form of the max-pool scatter
+__device__ __forceinline__ f32x4 pooled_grad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx, int n, int iy, int ix,
+                                              int cg, int c4n, int OH, int OW) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
+  for (int oy = oy0; oy <= oy1; ++oy) {
+    if (oy >= OH) continue;
+    const int kh = iy - (oy * 2 - 1);
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      if (ox >= OW) continue;
+      const int code = kh * 3 + (ix - (ox * 2 - 1));
+      const size_t o = ((size_t)(n * OH + oy) * OW + ox) * c4n + cg;
+      const uchar4 bsel = reinterpret_cast<const uchar4*>(idx)[o];
+      const f32x4 g = reinterpret_cast<const f32x4*>(dpool)[o];
+      if (bsel.x == code) acc[0] += g[0];
+      if (bsel.y == code) acc[1] += g[1];
+      if (bsel.z == code) acc[2] += g[2];
+      if (bsel.w == code) acc[3] += g[3];
+    }
+  }
+  return acc;
+}
+
+// PASS 0: per-tile (sum g, sum g * xhat) partials (layout of bn_reduce_kernel<1>);  PASS 1: dy = gamma * invstd * (g - db/M - xhat * dg/M)
+template <int PASS>
+__global__ __launch_bounds__(256) void bn_bwd_pooled_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                             const float* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                                             const float* __restrict__ dbeta, float* __restrict__ out, int N, int H,
+                                                             int W, int C, int OH, int OW, int tile_rows) {
+  __shared__ f32x4 red[2][256];
+  const int c4n = C >> 2, M = N * H * W;
+  const int cg = threadIdx.x % c4n, rl = threadIdx.x / c4n, nrl = 256 / c4n;
+  const int r0 = blockIdx.x * tile_rows, r1 = min(M, r0 + tile_rows);
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, dg = s0, db = s0;
+  if (PASS == 1) {
+    const float invM = 1.0f / (float)M;
+    dg = reinterpret_cast<const f32x4*>(dgamma)[cg] * invM;
+    db = reinterpret_cast<const f32x4*>(dbeta)[cg] * invM;
+  }
+  for (int r = r0 + rl; r < r1; r += nrl) {
+    const int ix = r % W, t = r / W, iy = t % H, n = t / H;
+    const size_t i = (size_t)r * c4n + cg;
+    const f32x4 xv = reinterpret_cast<const f32x4*>(y)[i];
+    const f32x4 a = bn_val(xv, mu, is, ga, be);
+    f32x4 g = pooled_grad(dpool, idx, n, iy, ix, cg, c4n, OH, OW);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+    const f32x4 xhat = (xv - mu) * is;
+    if (PASS == 0) {
+      s0 += g;
+      s1 += g * xhat;
+    } else {
+      reinterpret_cast<f32x4*>(out)[i] = ga * is * (g - db - xhat * dg);
+    }
+  }
+  if (PASS == 0) {
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0) {
+      for (int k = 1; k < nrl; ++k) {
+        s0 += red[0][k * c4n + cg];
+        s1 += red[1][k * c4n + cg];
+      }
+      reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.x * 2 + 0) * C)[cg] = s0;
+      reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.x * 2 + 1) * C)[cg] = s1;
+    }
   }
 }
 
@@ -379,5 +517,46 @@ extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float*
   bn_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(dout, relu_out, x, mean, invstd, gamma, dgamma, dbeta, dx, g_out, n4,
                                                    C / 4, 1.0f / (float)M);
   MLA_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_bn_relu_maxpool_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                       float* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+  if (int rc = bn_check("mla_bn_relu_maxpool_fwd", N * H * W, C)) return rc;
+  MLA_REQUIRE(y && mean && invstd && gamma && beta && out && idx && N > 0 && H > 0 && W > 0, "mla_bn_relu_maxpool_fwd: bad argument");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const size_t n4 = (size_t)N * OH * OW * C / 4;
+  bn_relu_maxpool_fwd_kernel<<<ew_grid(n4), 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, idx, N, H, W, C, OH, OW);
+  MLA_CHECK_LAUNCH("bn_relu_maxpool_fwd_kernel");
+  return MLA_OK;
+}
+
+extern "C" int mla_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const float* y, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, float* dy, float* dgamma, float* dbeta, float* ws, int N,
+                                 int H, int W, int C, void* stream) {
+  const long Ml = (long)N * H * W;
+  MLA_REQUIRE(Ml > 0 && Ml < (1L << 31), "mla_bn_bwd_pooled: bad dims");
+  const int M = (int)Ml;
+  if (int rc = bn_check("mla_bn_bwd_pooled", M, C)) return rc;
+  MLA_REQUIRE(dpool && idx && y && mean && invstd && gamma && beta && dy && dgamma && dbeta && ws, "mla_bn_bwd_pooled: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const int tr = bn_tile_rows(M), nt = cdiv(M, tr);
+  bn_bwd_pooled_kernel<0><<<nt, 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, nullptr, nullptr, ws, N, H, W, C, OH, OW, tr);
+  MLA_CHECK_LAUNCH("bn_bwd_pooled_kernel<0>");
+  if (nt <= BN_ONE_MAXT) {
+    bn_finalize_tiles_kernel<float, 0><<<cdiv(C, 16), 256, 0, st>>>(ws, nt, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+  } else {
+    double* scratch = reinterpret_cast<double*>(ws + (size_t)nt * 2 * C);
+    const int S = bn_red_chunks(nt);
+    bn_tiles_stage1_kernel<float><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(ws, nt, C, scratch);
+    MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
+    bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
+    MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  }
+  // the apply pass walks the same row tiles (a tile's pooled-gradient reads are then L2 hits of its own first pass)
+  bn_bwd_pooled_kernel<1><<<nt, 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, N, H, W, C, OH, OW, tr);
+  MLA_CHECK_LAUNCH("bn_bwd_pooled_kernel<1>");
   return MLA_OK;
 }

@@ -48,6 +48,8 @@ PROTOTYPES = {
     "mla_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mla_bn_bwd_ws_elems": (_Z, [_I, _I]),
     "mla_bn_bwd": (_I, [_P] * 11 + [_I, _I, _P]),
+    "mla_bn_relu_maxpool_fwd": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
+    "mla_bn_bwd_pooled": (_I, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "mla_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mla_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mla_avgpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -233,10 +233,9 @@ class ResNet18Encoder(FlatModule):
         hp, wp = ops.conv_out(h1, 3, 2, 1), ops.conv_out(w1, 3, 2, 1)
         ws["x0_shape"] = (N, H, W, cin0)
         ws["y_stem"] = torch.empty((N, h1, w1, 64), **f32)
-        ws["a_stem"] = torch.empty((N, h1, w1, 64), **f32)
         ws["p0"] = torch.empty((N, hp, wp, 64), **f32)
         ws["pool_idx"] = torch.empty((N, hp, wp, 64), device=dev, dtype=torch.uint8)
-        max_act = N * h1 * w1 * 64
+        max_act = N * hp * wp * 64          # the stem's ReLU output / its gradient are never materialised (fused kernels)
         max_partial = ops.conv2d_fwd_partial_elems(N, H, W, cin0, 64, 7, 7, 2, 3)
         max_wgrad = ops.conv2d_wgrad_ws_bytes(N, H, W, cin0, 64, 7, 7, 2, 3)
         max_bnws = ops.bn_bwd_ws_elems(N * h1 * w1, 64)
@@ -336,6 +335,41 @@ class ResNet18Encoder(FlatModule):
         ops.bn_apply(y, mean, invstd, self.p[bn + ".weight"], self.p[bn + ".bias"], out, M, C, relu, residual=residual,
                      stream=st)
 
+    def _stem(self, ws, st) -> None:
+        """p0 = maxpool(relu(bn1(conv1(x0)))): BN + ReLU are applied inside the max-pool, the (N,112,112,64)-sized ReLU
+        output is never written (backbone.py:149-152)."""
+        w = self.p["conv1.weight"]
+        wsp = self.wsp.get("conv1")
+        x, y = ws["x0"], ws["y_stem"]
+        ga, be = self.p["bn1.weight"], self.p["bn1.bias"]
+        if not self.training:
+            if wsp is not None:
+                ops.conv2d_fwd_split(x, wsp[0], w.shape, 2, 3, y=y, stream=st)
+            else:
+                ops.conv2d_fwd(x, w, 2, 3, y=y, stream=st)
+            ops.bn_relu_maxpool_fwd(y, self.rm["bn1"], self.rinv["bn1"], ga, be, ws["p0"], ws["pool_idx"], stream=st)
+            return
+        if wsp is not None:
+            _, tiles = ops.conv2d_fwd_split(x, wsp[0], w.shape, 2, 3, y=y, bn_partial=ws["partial"], stream=st)
+        else:
+            _, tiles = ops.conv2d_fwd(x, w, 2, 3, y=y, bn_partial=ws["partial"], stream=st)
+        mean, invstd = ws["stats"]["bn1"]
+        ops.bn_finalize(ws["partial"], tiles, y.numel() // 64, 64, mean, invstd, self.rm["bn1"], self.rv["bn1"], stream=st)
+        self.num_batches_tracked["bn1"] += 1
+        ops.bn_relu_maxpool_fwd(y, mean, invstd, ga, be, ws["p0"], ws["pool_idx"], stream=st)
+
+    def stem_relu(self, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """relu(bn1(conv1 output)) of the live forward, rebuilt on demand (tests / inspection; the step never forms it).
+        gamma / beta: bn1's affine parameters AT THE TIME OF THAT FORWARD if an optimizer step has changed them since."""
+        ws = self._ws
+        y = ws["y_stem"]
+        mean, invstd = ws["stats"]["bn1"] if self.training else (self.rm["bn1"], self.rinv["bn1"])
+        ga = self.p["bn1.weight"] if gamma is None else gamma.to(y.device, torch.float32).contiguous()
+        be = self.p["bn1.bias"] if beta is None else beta.to(y.device, torch.float32).contiguous()
+        out = torch.empty_like(y)
+        ops.bn_apply(y, mean, invstd, ga, be, out, y.numel() // 64, 64, True)
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,1,H,W) audio or (B,3,T,H,W) visual, fp32, reference layout.  Returns the NHWC feature
         map (N,h,w,512) of layer4 (backbone.py:142-160); activations are kept for backward()."""
@@ -366,8 +400,7 @@ class ResNet18Encoder(FlatModule):
             if "x0" not in ws:
                 ws["x0"] = torch.empty((N, H, W, 1), device=self.device, dtype=torch.float32)
             ws["x0"].copy_(x.view(N, H, W, 1))
-        self._conv_bn(ws, st, ws["x0"], "conv1", 2, 3, ws["y_stem"], ws["a_stem"], relu=True)   # :149-151
-        ops.maxpool_fwd(ws["a_stem"], ws["p0"], ws["pool_idx"], stream=st)                      # :152
+        self._stem(ws, st)                                                                       # :149-152
         cur = ws["p0"]
         for blk in ws["blocks"]:                                                                 # :154-157
             pre = blk["pre"]
@@ -460,11 +493,10 @@ class ResNet18Encoder(FlatModule):
                 self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx, residual=d, relu_src=mask)
             G[0], G[3] = G[3], G[0]
         # stem: maxpool -> relu -> bn1 -> conv1
-        a_stem = ws["a_stem"]
         dpool = G[0][:ws["p0"].numel()].view(ws["p0"].shape)
-        dstem = G[1][:a_stem.numel()].view(a_stem.shape)
-        ops.maxpool_bwd(dpool, ws["pool_idx"], dstem, a_stem.shape, relu_src=a_stem, stream=st)
-        self._bn_bwd(ws, st, "bn1", dstem, ws["y_stem"], DY["conv1"])
+        mean, invstd = ws["stats"]["bn1"]
+        ops.bn_bwd_pooled(dpool, ws["pool_idx"], ws["y_stem"], mean, invstd, self.p["bn1.weight"], self.p["bn1.bias"],
+                          DY["conv1"], self.g["bn1.weight"], self.g["bn1.bias"], ws["bn_ws"], stream=st)
         self._wgrad(ws, ws["x0"], DY["conv1"], "conv1", 2, 3)
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)      # all gradients complete before SGD / all-reduce

@@ -287,6 +287,30 @@ def bn_bwd(dout, x, mean, invstd, gamma, dx, dgamma, dbeta, ws, M: int, C: int, 
         TIMER.end("bn_bwd", 20.0 * M * C, t0, moved=20.0 * M * C)
 
 
+def bn_relu_maxpool_fwd(y, mean, invstd, gamma, beta, out, idx, stream: Optional[int] = None) -> None:
+    """maxpool3x3s2(relu(bn(y))) without materialising the ReLU output (stem, backbone.py:150-152)."""
+    N, H, W, C = y.shape
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_bn_relu_maxpool_fwd(_p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(out),
+                                              _p(idx, torch.uint8), N, H, W, C, stream or cur_stream()),
+          "mla_bn_relu_maxpool_fwd")
+    if t0 is not None:   # read y once, write the pooled quarter + its index bytes
+        by = 4.0 * N * H * W * C + 5.0 * out.numel()
+        TIMER.end("bn_relu_maxpool_fwd", by, t0, moved=by)
+
+
+def bn_bwd_pooled(dpool, idx, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, ws, stream: Optional[int] = None) -> None:
+    """BatchNorm backward fed by the pooled gradient (max-pool scatter + ReLU mask recomputed on the fly)."""
+    N, H, W, C = y.shape
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_bn_bwd_pooled(_p(dpool), _p(idx, torch.uint8), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta),
+                                        _p(dy), _p(dgamma), _p(dbeta), _p(ws), N, H, W, C, stream or cur_stream()),
+          "mla_bn_bwd_pooled")
+    if t0 is not None:   # y twice, dy once, the pooled gradient + index twice
+        by = 12.0 * N * H * W * C + 10.0 * dpool.numel()
+        TIMER.end("bn_bwd_pooled", by, t0, moved=by)
+
+
 # ---- pooling ------------------------------------------------------------------------------------
 def maxpool_fwd(x: torch.Tensor, y: torch.Tensor, idx: torch.Tensor, stream: Optional[int] = None) -> None:
     N, H, W, C = x.shape

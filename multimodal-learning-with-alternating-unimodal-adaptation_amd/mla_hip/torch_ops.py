@@ -110,6 +110,28 @@ def maxpool3x3s2_bwd(dy, idx, x_shape, relu_src=None):
     return dx
 
 
+@_op("bn_relu_maxpool_fwd(Tensor y, Tensor mean, Tensor invstd, Tensor gamma, Tensor beta) -> (Tensor, Tensor)")
+def bn_relu_maxpool_fwd(y, mean, invstd, gamma, beta):
+    """maxpool3x3s2(relu(bn(y))) for the stem (backbone.py:150-152) without materialising the ReLU output."""
+    N, H, W, C = y.shape
+    oh, ow = ops.conv_out(H, 3, 2, 1), ops.conv_out(W, 3, 2, 1)
+    out = _f32((N, oh, ow, C), y)
+    idx = torch.empty((N, oh, ow, C), device=y.device, dtype=torch.uint8)
+    ops.bn_relu_maxpool_fwd(y, mean, invstd, gamma, beta, out, idx)
+    return out, idx
+
+
+@_op("bn_bwd_pooled(Tensor dpool, Tensor idx, Tensor y, Tensor mean, Tensor invstd, Tensor gamma, Tensor beta) -> (Tensor, Tensor, Tensor)")
+def bn_bwd_pooled(dpool, idx, y, mean, invstd, gamma, beta):
+    """Backward of bn_relu_maxpool_fwd: (dy, dgamma, dbeta)."""
+    N, H, W, C = y.shape
+    dy = torch.empty_like(y)
+    dg, db = _f32((C,), y), _f32((C,), y)
+    ws = _f32((ops.bn_bwd_ws_elems(N * H * W, C),), y)
+    ops.bn_bwd_pooled(dpool, idx, y, mean, invstd, gamma, beta, dy, dg, db, ws)
+    return dy, dg, db
+
+
 @_op("avgpool_fwd(Tensor x, int groups) -> Tensor")
 def avgpool_fwd(x, groups):
     """x (..., C) viewed as (groups, P, C) -> (groups, C): adaptive_avg_pool2d / 3d + flatten."""

@@ -327,6 +327,68 @@ def test_maxpool(ops, N, H, W, C):
     assert_close(nchw(dx.cpu()), O.maxpool3x3s2_bwd(dy, idx_ref, x.shape), atol=1e-6, name="maxpool bwd ties")
 
 
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 12, 64), (3, 9, 7, 64), (1, 2, 2, 128), (4, 112, 40, 64)])
+def test_stem_fused(ops, N, H, W, C):
+    """The fused stem kernels (BN + ReLU inside the max-pool; BN backward fed by the pooled gradient) against (1) the
+    unfused kernel sequence bn_apply -> maxpool_fwd / maxpool_bwd -> bn_bwd (same decisions bit for bit, same pooled output
+    bit for bit) and (2) the oracle (backbone.py:150-152 and its autograd)."""
+    M = N * H * W
+    x = O.portable_normal(M + C, (N, C, H, W), stream=1, mean=0.2, std=1.3)
+    gamma = O.portable_normal(M + C, (C,), stream=2, mean=1.0, std=0.2)
+    beta = O.portable_normal(M + C, (C,), stream=3, std=0.3)
+    xd = nhwc(x).cuda()
+    part = torch.empty(ops.bn_stats_partial_elems(M, C), device="cuda")
+    tiles = ops.bn_stats_partial(xd.view(M, C), M, C, part)
+    mean, invstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_finalize(part, tiles, M, C, mean, invstd, None, None)
+    ga, be = gamma.cuda(), beta.cuda()
+    # unfused
+    a = torch.empty_like(xd)
+    ops.bn_apply(xd.view(M, C), mean, invstd, ga, be, a.view(M, C), M, C, True)
+    OH, OW = ops.conv_out(H, 3, 2, 1), ops.conv_out(W, 3, 2, 1)
+    p_u = torch.empty((N, OH, OW, C), device="cuda")
+    i_u = torch.empty((N, OH, OW, C), device="cuda", dtype=torch.uint8)
+    ops.maxpool_fwd(a, p_u, i_u)
+    # fused
+    p_f, i_f = torch.empty_like(p_u), torch.empty_like(i_u)
+    ops.bn_relu_maxpool_fwd(xd, mean, invstd, ga, be, p_f, i_f)
+    assert torch.equal(p_f, p_u), "fused stem forward: pooled output differs from bn_apply -> maxpool"
+    assert torch.equal(i_f, i_u), "fused stem forward: max-pool decisions differ"
+    # oracle forward
+    y_ref, mean_ref, invstd_ref = O.bn_train_fwd(x, gamma, beta, torch.zeros(C), torch.ones(C))
+    a_ref = torch.relu(y_ref)
+    p_ref, idx_ref = O.maxpool3x3s2_fwd(a_ref)
+    assert_close(nchw(p_f.cpu()), p_ref, atol=2e-6, rtol=1e-5, name="fused stem forward vs oracle")
+
+    dpool = O.portable_normal(M + C, tuple(p_ref.shape), stream=4)
+    dpd = nhwc(dpool).cuda()
+    ws = torch.empty(ops.bn_bwd_ws_elems(M, C), device="cuda")
+    dstem = torch.empty_like(xd)
+    ops.maxpool_bwd(dpd, i_u, dstem, (N, H, W, C), relu_src=a)
+    dy_u, dg_u, db_u = torch.empty_like(xd), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_bwd(dstem.view(M, C), xd.view(M, C), mean, invstd, ga, dy_u.view(M, C), dg_u, db_u, ws, M, C)
+    dy_f, dg_f, db_f = torch.empty_like(xd), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_bwd_pooled(dpd, i_f, xd, mean, invstd, ga, be, dy_f, dg_f, db_f, ws)
+    scale = dy_u.abs().max().item()
+    assert_close(dg_f, dg_u, atol=1e-5 * dg_u.abs().max().item(), name="fused stem dgamma vs unfused")
+    assert_close(db_f, db_u, atol=1e-5 * db_u.abs().max().item(), name="fused stem dbeta vs unfused")
+    assert_close(dy_f, dy_u, atol=2e-6 * scale, name="fused stem dy vs unfused")
+    # oracle backward with the HIP path's own decisions (flip-immune): scatter through idx, mask, BN backward
+    code = nchw(i_f.cpu()).long()
+    oy = torch.arange(OH).view(1, 1, OH, 1)
+    ox = torch.arange(OW).view(1, 1, 1, OW)
+    flat = (oy * 2 - 1 + code // 3) * W + (ox * 2 - 1 + code % 3)
+    g_ref = O.maxpool3x3s2_bwd(dpool, flat, x.shape) * (nchw(a.cpu()) > 0)
+    dx_ref, dgamma_ref, dbeta_ref = O.bn_train_bwd(g_ref, x, gamma, mean_ref, invstd_ref)
+    assert_close(dg_f, dgamma_ref, atol=1e-4, rtol=5e-5, name="fused stem dgamma vs oracle")
+    assert_close(db_f, dbeta_ref, atol=1e-4, rtol=5e-5, name="fused stem dbeta vs oracle")
+    assert_close(nchw(dy_f.cpu()), dx_ref, atol=2e-6 * max(scale, 1.0), rtol=5e-5, name="fused stem dy vs oracle")
+    # the torch.ops face
+    p_t, i_t = torch.ops.mla_hip.bn_relu_maxpool_fwd(xd, mean, invstd, ga, be)
+    dy_t, dg_t, db_t = torch.ops.mla_hip.bn_bwd_pooled(dpd, i_t, xd, mean, invstd, ga, be)
+    assert torch.equal(p_t, p_f) and torch.equal(i_t, i_f) and torch.equal(dy_t, dy_f) and torch.equal(dg_t, dg_f)
+
+
 @pytest.mark.parametrize("B,T,h,w,C", [(4, 1, 32, 4, 512), (4, 3, 7, 7, 512), (3, 2, 1, 1, 512), (2, 1, 5, 3, 64)])
 def test_avgpool(ops, B, T, h, w, C):
     f = torch.relu(O.portable_normal(B + T + h, (B * T, C, h, w), stream=1))

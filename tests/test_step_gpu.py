@@ -135,7 +135,7 @@ def test_step_vs_oracle_all_grads(B, spec_hw, T, img_hw, conv_math):
             for k, want in ref["grads_" + enc].items():
                 assert_close_robust(got[k], want, rel_l2=5e-2, elem_tol=1.0, frac=0.0, name=f"s{s} grad {enc}.{k}")
             # (2) teacher-forced, element-wise
-            cache = oracle_cache_from_hip(net)
+            cache = oracle_cache_from_hip(net, hip_before[enc])
             dX = head._bufs(B, slot)["dX"].cpu()
             fshape = cache["layer4.1.out"].shape
             dout = O.audio_pool_bwd(dX, fshape) if enc == "audio" else O.visual_pool_bwd(dX, fshape, B)

@@ -32,17 +32,18 @@ def assert_close_robust(got, want, rel_l2, elem_tol, frac=0.97, name=""):
     return err / max(ref, 1e-30)
 
 
-def oracle_cache_from_hip(enc):
+def oracle_cache_from_hip(enc, params_before=None):
     """Rebuild the oracle's backward cache (NCHW, oracle/mla_oracle.py:resnet18_fwd) from the HIP encoder's
     saved forward state.  Feeding it to O.resnet18_bwd gives a backward that uses exactly the same ReLU /
-    max-pool decisions as the HIP path, so gradients can be compared element-wise (flip-immune)."""
+    max-pool decisions as the HIP path, so gradients can be compared element-wise (flip-immune).
+    params_before: the encoder's reference-layout parameters at the time of that forward (the stem's ReLU output is never
+    stored by the HIP path; it is rebuilt from the saved conv output, which needs bn1's affine parameters of that moment)."""
     ws = enc._ws
     to = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
     st = lambda bn: tuple(v.cpu() for v in ws["stats"][bn])
-    cache = {"modality": enc.modality, "x0": to(ws["x0"]), "stem_relu": to(ws["a_stem"])}
+    cache = {"modality": enc.modality, "x0": to(ws["x0"]), "stem_relu": to(enc.stem_relu(*((params_before["bn1.weight"], params_before["bn1.bias"]) if params_before else ())))}
     cache["bn1"] = (to(ws["y_stem"]),) + st("bn1")
-    a = ws["a_stem"]
-    N, H, W, C = a.shape
+    N, H, W, C = ws["y_stem"].shape
     code = to(ws["pool_idx"]).long()                              # (N,C,OH,OW), kh*3+kw
     OH, OW = code.shape[2:]
     oy = torch.arange(OH).view(1, 1, OH, 1)
