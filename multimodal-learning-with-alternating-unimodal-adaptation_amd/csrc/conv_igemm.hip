@@ -242,11 +242,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
   const int tilesI = SCALAR_A ? (g.K + BI - 1) / BI : g.C / BI, tilesJ = g.CO / BJ;
-  int b = blockIdx.x;
+  // all workgroups of one pixel span (every tap and channel tile) on ONE XCD: they gather the same X / dY rows, which its
+  // L2 then serves 9 x tiles times; in dispatch order they would be spread round-robin over the 8 XCDs (8 L2 fills per span).
+  // Same-box A/B: 64x64 tiles (layer1) -4...5 %, 128x128 tiles +-0.
+  const int lwg = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int by = lwg / (int)gridDim.x;
+  int b = lwg - by * (int)gridDim.x;
   const int tj = b % tilesJ; b /= tilesJ;
   const int ti = b % tilesI; b /= tilesI;
   const int t = b;  // tap (0 in scalar mode)
-  const int m_begin = blockIdx.y * span, m_end = min(g.M, m_begin + span);
+  const int m_begin = by * span, m_end = min(g.M, m_begin + span);
   const int gH = g.H, gW = g.W, gC = g.C, gCO = g.CO;
 
   f32x16 acc[MI][NI];
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float* __restrict__
   }
 
   const int KR = SCALAR_A ? g.K : gC;  // rows of one tap slab
-  float* slab = part + ((size_t)blockIdx.y * (SCALAR_A ? 1 : g.T) + t) * KR * gCO;
+  float* slab = part + ((size_t)by * (SCALAR_A ? 1 : g.T) + t) * KR * gCO;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

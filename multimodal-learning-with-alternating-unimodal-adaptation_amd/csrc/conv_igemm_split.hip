@@ -34,13 +34,34 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // low hal
   f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// a - b as ONE v_sub_f32: the SLP vectoriser otherwise pairs the two residual subtractions of split_pair into v_pk_add_f32,
+// which costs more issue time beside MFMAs than the two scalar subtractions it replaces (gather-GEMM forward / input gradient:
+// -0.5...1 % time in a same-box A/B; the weight-gradient kernels keep the compiler's choice)
+__device__ __forceinline__ float sub_scalar(float a, float b) {
+  float r;
+  asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // two fp32 values -> three packed bf16 pairs with x = hi + mid + lo exactly
+template <bool NOPK = false>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
   hi = cvt_pk_bf16(x0, x1);
-  float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  float r0, r1;
+  if constexpr (NOPK) {
+    r0 = sub_scalar(x0, __uint_as_float(hi << 16));
+    r1 = sub_scalar(x1, __uint_as_float(hi & 0xffff0000u));
+  } else {
+    r0 = x0 - __uint_as_float(hi << 16);
+    r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  }
   mid = cvt_pk_bf16(r0, r1);
-  r0 -= __uint_as_float(mid << 16);
-  r1 -= __uint_as_float(mid & 0xffff0000u);
+  if constexpr (NOPK) {
+    r0 = sub_scalar(r0, __uint_as_float(mid << 16));
+    r1 = sub_scalar(r1, __uint_as_float(mid & 0xffff0000u));
+  } else {
+    r0 -= __uint_as_float(mid << 16);
+    r1 -= __uint_as_float(mid & 0xffff0000u);
+  }
   lo = cvt_pk_bf16(r0, r1);
 }
 
@@ -118,8 +139,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
   const int nIter = g.T * (gC / BKS);   // K stages: taps x channel chunks
   const unsigned plane_bytes = g.w_bytes / 2;   // one bf16 plane of the whole weight tensor
 
-  f32x4 areg[APASS];
-  bchunk_t breg[3][BPASS];
+  struct Stage { f32x4 a[APASS]; bchunk_t b[3][BPASS]; };   // one K stage of both operands in registers, on its way to LDS
+  Stage rs0;
   const rsrc_t xr = make_rsrc(X, g.x_bytes), wr = make_rsrc(Wsp, 3 * plane_bytes);
   const int arow = tid / ACH, ac = tid % ACH;       // A: row within a pass, float4 chunk
   const int brow = tid >> 2, bq = tid & 3;          // B: row within a pass, chunk
@@ -143,7 +164,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
   // (tap, first channel) of the next tile to load, carried as counters instead of it / cpt (+1-2 %; going further and
   // reading per-tap byte offsets from an LDS table is 5-10 % SLOWER: the lgkmcnt(0) wait drains the fragment reads)
   int ld_t = 0, ld_c0 = 0;
-  auto load_tiles = [&](int) {       // tiles are loaded strictly in order 0, 1, 2, ...
+  auto load_tiles = [&](Stage& rs) {       // tiles are loaded strictly in order 0, 1, 2, ...
     const int t = ld_t, c0 = ld_c0;
     ld_c0 += BKS;
     if (ld_c0 == gC) { ld_c0 = 0; ++ld_t; }
@@ -151,15 +172,15 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
     const unsigned toff = (unsigned)(((tap_dy(tp) * gW + tap_dx(tp)) * gC + c0) * 4);       // wave-uniform (SGPR)
 #pragma unroll
     for (int p = 0; p < APASS; ++p)
-      areg[p] = buf_load4(xr, ((tmask[p] >> t) & 1u) ? rowoff[p] + toff : OOB_OFF, 0);
+      rs.a[p] = buf_load4(xr, ((tmask[p] >> t) & 1u) ? rowoff[p] + toff : OOB_OFF, 0);
     const unsigned wsoff = (unsigned)(((tap_wt(tp) * gCO + tn * BN) * gC + c0) * 2);        // wave-uniform
     if (bact) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
-          if constexpr (BKS == 32) breg[pl][p] = buf_load4u(wr, boff[p], wsoff + pl * plane_bytes);
-          else breg[pl][p] = __builtin_amdgcn_raw_buffer_load_b64(wr, (int)boff[p], (int)(wsoff + pl * plane_bytes), 0);
+          if constexpr (BKS == 32) rs.b[pl][p] = buf_load4u(wr, boff[p], wsoff + pl * plane_bytes);
+          else rs.b[pl][p] = __builtin_amdgcn_raw_buffer_load_b64(wr, (int)boff[p], (int)(wsoff + pl * plane_bytes), 0);
         }
     }
   };
@@ -168,14 +189,14 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
                              : arow * LR + ((((ac >> 1) ^ ((arow >> 3) & 1)) << 2) + (ac & 1) * 2);
   const int b_st = BKS == 32 ? brow * LR + ((bq ^ ((brow >> 2) & 3)) << 2)
                              : brow * LR + ((((bq >> 1) ^ ((brow >> 3) & 1)) << 2) + (bq & 1) * 2);
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const Stage& rs) {
     unsigned* Ad = As + buf * ASZ + a_st;
     unsigned* Bd = Bs + buf * BSZ + b_st;
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
       unsigned h0, m0, l0, h1, m1, l1;
-      split_pair(areg[p][0], areg[p][1], h0, m0, l0);
-      split_pair(areg[p][2], areg[p][3], h1, m1, l1);
+      split_pair<true>(rs.a[p][0], rs.a[p][1], h0, m0, l0);
+      split_pair<true>(rs.a[p][2], rs.a[p][3], h1, m1, l1);
       unsigned* dst = Ad + p * AROWS * LR;
       *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
       *reinterpret_cast<u32x2*>(dst + BM * LR) = u32x2{m0, m1};
@@ -186,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
         for (int p = 0; p < BPASS; ++p)
-          *reinterpret_cast<bchunk_t*>(Bd + (pl * BN + p * BROWS) * LR) = breg[pl][p];
+          *reinterpret_cast<bchunk_t*>(Bd + (pl * BN + p * BROWS) * LR) = rs.b[pl][p];
     }
   };
 
@@ -219,9 +240,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
   Frags f0, f1;
 
   if (nIter > 0) {  // nIter == 0: a dgrad parity class no tap reaches (1x1 stride 2): epilogue only
-    load_tiles(0);
-    store_tiles(0);
-    if (nIter > 1) load_tiles(1);
+    load_tiles(rs0);
+    store_tiles(0, rs0);
+    if (nIter > 1) load_tiles(rs0);
   }
   __syncthreads();
   // Steady state is branch-free so the scheduler can interleave the staging work with the MFMAs; the last two
@@ -242,8 +263,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
     load_frags(cur, 0, f0);
     if constexpr (NKK == 2) load_frags(cur, 1, f1);   // both halves' fragments in flight before the first MFMA
     mma_frags(f0);
-    store_tiles(cur ^ 1);   // readers of that buffer finished before the previous barrier
-    load_tiles(it + 2);
+    store_tiles(cur ^ 1, rs0);   // readers of that buffer finished before the previous barrier
+    load_tiles(rs0);
     if constexpr (NKK == 2) mma_frags(f1);
     __syncthreads();
   }
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
     load_frags(cur, 0, f0);
     if constexpr (NKK == 2) load_frags(cur, 1, f1);
     mma_frags(f0);
-    store_tiles(cur ^ 1);
+    store_tiles(cur ^ 1, rs0);
     if constexpr (NKK == 2) mma_frags(f1);
     __syncthreads();
     ++it;
@@ -288,16 +309,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(const float* __rest
   constexpr int ASZ = 3 * BI * LROW, BSZ = 3 * BJ * LROW;
   __shared__ __attribute__((aligned(16))) unsigned As[2 * ASZ];
   __shared__ __attribute__((aligned(16))) unsigned Bs[2 * BSZ];
-  __shared__ unsigned rowoff[WGS_CHUNK];   // byte offset of the gathered X row (this block's tap, channel tile) or OOB_OFF
+  __shared__ unsigned rowoff[WGS_CHUNK];   // (64x64 tile with half the chunk = three workgroups per CU: 7-17 % slower, measured)
+                                           // byte offset of the gathered X row (this block's tap, channel tile) or OOB_OFF
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / WJ, wj = wave % WJ;
   const int tilesI = g.C / BI, tilesJ = g.CO / BJ;
-  int b = blockIdx.x;
+  // all workgroups of one pixel span (every tap and channel tile) on ONE XCD: they gather the same X / dY rows, which its
+  // L2 then serves 9 x tiles times; in dispatch order they would be spread round-robin over the 8 XCDs (8 L2 fills per span).
+  // Same-box A/B: 64x64 tiles (layer1) -4...5 %, 128x128 tiles +-0.
+  const int lwg = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  const int by = lwg / (int)gridDim.x;
+  int b = lwg - by * (int)gridDim.x;
   const int tj = b % tilesJ; b /= tilesJ;
   const int ti = b % tilesI; b /= tilesI;
   const int t = b;
-  const int m_begin = blockIdx.y * span, m_end = min(g.M, m_begin + span);
+  const int m_begin = by * span, m_end = min(g.M, m_begin + span);
   const int gH = g.H, gW = g.W, gC = g.C, gCO = g.CO;
   const int dy = tap_dy(g.tap[t]), dx = tap_dx(g.tap[t]);
 
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_kernel(const float* __rest
     }
   }
 
-  float* slab = part + ((size_t)blockIdx.y * g.T + t) * gC * gCO;
+  float* slab = part + ((size_t)by * g.T + t) * gC * gCO;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

@@ -11,6 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmla_hip.so")
+LIB_PATH = os.environ.get("MLA_HIP_LIB", LIB_PATH)      # A/B measurements of two builds on one box (scripts/ab_sweep.sh)
 
 
 class MLAHipError(RuntimeError):
