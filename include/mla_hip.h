@@ -88,6 +88,25 @@ int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float* y,
 int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float* dx,
                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            const float* residual, const float* relu_src, void* stream);
+
+/* Input gradient that also forms the reduction pass of the BatchNorm backward(s) consuming dx: for each request q (at most 2:
+ * the BatchNorm before this convolution in the forward pass, and a downsample BatchNorm beside it) the epilogue writes the
+ * per-tile column sums  sum dx  and  sum dx * (x_q - mean_q) * invstd_q  to partial_q[tile][2][Cin] (floats; size
+ * mla_conv2d_dgrad_bn_partial_elems; *bn_tiles = number of tiles written), which mla_bn_bwd_from_partial then finalizes and
+ * applies.  Saves re-reading dx and x in a separate reduction pass.  nreq = 0: identical to mla_conv2d_dgrad[_split]. */
+typedef struct mla_bn_reduce_req {
+  const float* x;        /* the BatchNorm's input (conv output), (N,H,W,Cin) like dx */
+  const float* mean;     /* its saved batch mean / inverse standard deviation, (Cin) */
+  const float* invstd;
+  float* partial;        /* out */
+} mla_bn_reduce_req;
+size_t mla_conv2d_dgrad_bn_partial_elems(int N, int H, int W, int Cin);
+int mla_conv2d_dgrad_bn(const float* dy, const float* w_hwio, float* dx, int N, int H, int W, int Cin, int Cout,
+                        int KH, int KW, int stride, int pad, const float* residual, const float* relu_src, float* wt_ws,
+                        const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, void* stream);
+int mla_conv2d_dgrad_split_bn(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
+                              int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
+                              const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, void* stream);
 /* weight gradient on the same arithmetic (both operands split in the kernel); workspace and reduce as mla_conv2d_wgrad */
 size_t mla_conv2d_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw_hwio,
@@ -116,6 +135,10 @@ int mla_bn_bwd(const float* dout, const float* relu_out, const float* x, const f
                const float* invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
                float* g_out, float* ws, int M, int C, void* stream);
 
+/* BatchNorm backward whose reduction pass was done by the producer of dout (mla_conv2d_dgrad[_split]_bn): finalize the
+ * `tiles` per-tile sums of `partial` into dgamma / dbeta, then dx = gamma * invstd * (dout - dbeta/M - xhat * dgamma/M). */
+int mla_bn_bwd_from_partial(const float* dout, const float* x, const float* mean, const float* invstd, const float* gamma,
+                            float* dx, float* dgamma, float* dbeta, float* partial, int tiles, int M, int C, void* stream);
 /* Stem conv1 -> bn1 -> relu -> maxpool (backbone.py:149-152) without materialising the ReLU output: the max-pool applies
  * BN + ReLU to y (NHWC conv output) on the fly; out (N,OH,OW,C), idx = window position 0..8 of the first maximum. */
 int mla_bn_relu_maxpool_fwd(const float* y, const float* mean, const float* invstd, const float* gamma,

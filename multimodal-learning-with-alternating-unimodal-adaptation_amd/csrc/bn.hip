@@ -520,6 +520,33 @@ extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float*
   return MLA_OK;
 }
 
+// BatchNorm backward whose reduction pass was done by the producer of dout (mla_conv2d_dgrad[_split]_bn): finalize the
+// `tiles` per-tile sums of `partial` (its scratch tail follows the tiles) into dgamma / dbeta, then the apply pass.
+extern "C" int mla_bn_bwd_from_partial(const float* dout, const float* x, const float* mean, const float* invstd,
+                                       const float* gamma, float* dx, float* dgamma, float* dbeta, float* partial, int tiles,
+                                       int M, int C, void* stream) {
+  if (int rc = bn_check("mla_bn_bwd_from_partial", M, C)) return rc;
+  MLA_REQUIRE(dout && x && mean && invstd && gamma && dx && dgamma && dbeta && partial && tiles > 0,
+              "mla_bn_bwd_from_partial: null pointer or no tiles");
+  hipStream_t st = (hipStream_t)stream;
+  if (tiles <= BN_ONE_MAXT) {
+    bn_finalize_tiles_kernel<float, 0><<<cdiv(C, 16), 256, 0, st>>>(partial, tiles, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+  } else {
+    double* scratch = reinterpret_cast<double*>(partial + (size_t)tiles * 2 * C);
+    const int S = bn_red_chunks(tiles);
+    bn_tiles_stage1_kernel<float><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(partial, tiles, C, scratch);
+    MLA_CHECK_LAUNCH("bn_tiles_stage1_kernel");
+    bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
+    MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+  }
+  const size_t n4 = (size_t)M * C / 4;
+  bn_bwd_apply_kernel<<<ew_grid(n4), 256, 0, st>>>(dout, nullptr, x, mean, invstd, gamma, dgamma, dbeta, dx, nullptr, n4, C / 4,
+                                                   1.0f / (float)M);
+  MLA_CHECK_LAUNCH("bn_bwd_apply_kernel");
+  return MLA_OK;
+}
+
 extern "C" int mla_bn_relu_maxpool_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                        float* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
   if (int rc = bn_check("mla_bn_relu_maxpool_fwd", N * H * W, C)) return rc;

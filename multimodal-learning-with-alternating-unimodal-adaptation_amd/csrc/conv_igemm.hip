@@ -459,9 +459,20 @@ extern "C" int mla_conv2d_fwd(const float* x, const float* w, float* y, int N, i
   return launch_igemm(x, w, y, nullptr, nullptr, bn_partial, g, Cin % 64 != 0, cfg, (hipStream_t)stream);
 }
 
+extern "C" size_t mla_conv2d_dgrad_bn_partial_elems(int N, int H, int W, int Cin) {
+  // [tiles][2][Cin] floats, tiles <= ceil(pixels / 64) + one ragged tile per stride-2 parity class, + the reduce scratch tail
+  return ((size_t)cdiv((long)N * H * W, 64) + 4) * 2 * Cin + mla_bn_partial_scratch_elems(Cin);
+}
+
 extern "C" int mla_conv2d_dgrad(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
                                 int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
                                 float* wt_ws, void* stream) {
+  return mla_conv2d_dgrad_bn(dy, w, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, relu_src, wt_ws, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int mla_conv2d_dgrad_bn(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
+                                   int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
+                                   float* wt_ws, const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, void* stream) {
   if (int rc = check_conv("mla_conv2d_dgrad", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
   MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_dgrad: Cin=%d must be a multiple of 64 (the stem needs no dgrad)", Cin);
   MLA_REQUIRE(dy && w && dx && wt_ws, "mla_conv2d_dgrad: null pointer");
@@ -471,6 +482,7 @@ extern "C" int mla_conv2d_dgrad(const float* dy, const float* w, float* dx, int 
   // "input" of the gather-GEMM is dy (N,OH,OW,Cout); "output" is dx (N,H,W,Cin).  Stride 2: one launch per
   // output parity class, each with its own tile choice (measured: 25 % faster than all classes merged in one
   // launch with interleaved workgroups, 1.56 vs 2.09 ms over the six stride-2 convs).
+  int tiles = 0;   // row tiles launched so far = first tile index of the next parity class in the BatchNorm partial buffers
   for (int py = 0; py < stride; ++py)
     for (int px = 0; px < stride; ++px) {
       IGemmGeom g;
@@ -480,8 +492,11 @@ extern "C" int mla_conv2d_dgrad(const float* dy, const float* w, float* dx, int 
       const long Mc = g.M;
       const int wt = T > 0 ? T : 1;
       const int cfg = pick_cfg(&Mc, &wt, 1, Cin, false);
+      if (int rc = attach_bn_reqs("mla_conv2d_dgrad_bn", g, reqs, nreq, tiles)) return rc;
       if (int rc = launch_igemm(dy, wt_ws, dx, residual, relu_src, nullptr, g, false, cfg, st)) return rc;
+      tiles += cdiv(g.M, cfg_bm(cfg));
     }
+  if (bn_tiles) *bn_tiles = tiles;
   return MLA_OK;
 }
 

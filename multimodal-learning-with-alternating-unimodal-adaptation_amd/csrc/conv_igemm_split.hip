@@ -627,17 +627,27 @@ extern "C" int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float*
 extern "C" int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
                                       int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
                                       void* stream) {
+  return mla_conv2d_dgrad_split_bn(dy, wsplit, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, relu_src, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int mla_conv2d_dgrad_split_bn(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
+                                         int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
+                                         const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, void* stream) {
   if (int rc = check_conv("mla_conv2d_dgrad_split", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
   MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_dgrad_split: Cin=%d must be a multiple of 64 (the stem needs no dgrad)", Cin);
   MLA_REQUIRE(dy && wsplit && dx, "mla_conv2d_dgrad_split: null pointer");
+  int tiles = 0;
   for (int py = 0; py < stride; ++py)
     for (int px = 0; px < stride; ++px) {
       IGemmGeom g;
       make_dgrad_geom(g, py, px, N, H, W, Cin, Cout, KH, KW, stride, pad);
       if (g.M <= 0) continue;
       const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1);
+      if (int rc = attach_bn_reqs("mla_conv2d_dgrad_split_bn", g, reqs, nreq, tiles)) return rc;
       if (int rc = launch_split(dy, wsplit, dx, residual, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
+      tiles += cdiv(g.M, scfg_bm(cfg));
     }
+  if (bn_tiles) *bn_tiles = tiles;
   return MLA_OK;
 }
 

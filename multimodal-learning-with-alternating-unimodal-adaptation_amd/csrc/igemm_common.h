@@ -19,6 +19,15 @@ struct IGemmGeom {
   unsigned x_bytes, w_bytes, y_bytes;   // byte sizes of the gathered tensor, the weights and the second operand (wgrad: dY)
   int epi;                 // 0: MASK = ReLU mask (v = MASK > 0 ? v : 0);  1: MASK = GELU pre-activation u (v *= gelu'(u))
   int tap[MAX_TAPS];       // (dy & 0xff) | (dx & 0xff) << 8 | wt << 16   (int32: read with s_load_dword)
+  // Input-gradient launches only: up to two BatchNorm layers whose backward consumes the tensor this launch writes (the
+  // BatchNorm that follows in the backward chain, and the downsample BatchNorm beside it).  For each, the epilogue also forms the
+  // per-tile column sums  sum v  and  sum v * xhat,  xhat = (bn_x - bn_mean) * bn_invstd  (v = the value it stores), which is the
+  // whole reduction pass of that BatchNorm backward: part[bn_tile0 + tile][2][CO] floats, the layout of bn_reduce_kernel<1>.
+  const float* bn_x[2];
+  const float* bn_mean[2];
+  const float* bn_invstd[2];
+  float* bn_part[2];
+  int bn_tile0;
 };
 
 // Gathers use raw buffer loads: the hardware range check of the buffer descriptor returns 0 for any
@@ -52,9 +61,9 @@ __device__ __forceinline__ int tap_wt(int t) { return t >> 16; }
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue shared by the gather-GEMM kernels: residual add, bias, ReLU/GELU backward mask, GELU second
-// output, store, fused BatchNorm column statistics.  acc is in the 32x32 MFMA C/D layout
-// (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  `red` is >= 2*WM*BN floats of LDS that no
-// wave reads any more (the caller's trailing __syncthreads()).
+// output, store, fused BatchNorm column statistics (forward) or BatchNorm-backward reductions (input gradient).  acc is in
+// the 32x32 MFMA C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  `red` is >= 4*WM*BN floats of LDS
+// that no wave reads any more (the caller's trailing __syncthreads()).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int4* rowinfo, float* red,
@@ -72,6 +81,18 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / 
   double csum[NI], csq[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) csum[ni] = csq[ni] = 0.0;
+  // fused BatchNorm-backward reductions (see IGemmGeom::bn_x): b0 = sum v (shared by both requests), b1[q] = sum v * xhat_q
+  const bool bnq0 = g.bn_x[0] != nullptr, bnq1 = g.bn_x[1] != nullptr;
+  float b0[NI], b1[2][NI], bmu[2][NI], bis[2][NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    b0[ni] = b1[0][ni] = b1[1][ni] = 0.f;
+    const int c = tn * BN + wn * (BN / WN) + ni * 32 + j;
+    bmu[0][ni] = bnq0 ? g.bn_mean[0][c] : 0.f;
+    bis[0][ni] = bnq0 ? g.bn_invstd[0][c] : 0.f;
+    bmu[1][ni] = bnq1 ? g.bn_mean[1][c] : 0.f;
+    bis[1][ni] = bnq1 ? g.bn_invstd[1][c] : 0.f;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     size_t off[16];
@@ -122,6 +143,26 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / 
         for (int ni = 0; ni < NI; ++ni)
           if (ok[e]) Y2[off[e] + ni * 32] = gelu_fwd(acc[mi][ni][e]);
     }
+    if (bnq0) {  // rows past M may hold residual garbage (their loads read row 0): they are masked out of the sums
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q == 1 && !bnq1) break;
+        const float* __restrict__ bx = g.bn_x[q];
+        float xv[16][NI];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) xv[e][ni] = bx[off[e] + ni * 32];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const float v = ok[e] ? acc[mi][ni][e] : 0.f;
+            if (q == 0) b0[ni] += v;
+            b1[q][ni] += v * ((xv[e][ni] - bmu[q][ni]) * bis[q][ni]);
+          }
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e)
 #pragma unroll
@@ -134,6 +175,37 @@ __device__ __forceinline__ void igemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / 
         }
         if (ok[e]) Y[off[e] + ni * 32] = v;
       }
+  }
+  if (bnq0) {  // per-tile column sums of the fused BatchNorm-backward reductions: [tile][2][CO] floats per request
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      b0[ni] += __shfl_xor(b0[ni], 32, 64);
+      b1[0][ni] += __shfl_xor(b1[0][ni], 32, 64);
+      b1[1][ni] += __shfl_xor(b1[1][ni], 32, 64);
+      if (h == 0) {
+        const int c = wn * (BN / WN) + ni * 32 + j;
+        red[(wm * 3 + 0) * BN + c] = b0[ni];
+        red[(wm * 3 + 1) * BN + c] = b1[0][ni];
+        red[(wm * 3 + 2) * BN + c] = b1[1][ni];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s += red[(w * 3 + 0) * BN + tid];
+        q0 += red[(w * 3 + 1) * BN + tid];
+        q1 += red[(w * 3 + 2) * BN + tid];
+      }
+      const size_t o = ((size_t)(g.bn_tile0 + tm) * 2) * gCO + tn * BN + tid;
+      g.bn_part[0][o] = s;
+      g.bn_part[0][o + gCO] = q0;
+      if (bnq1) {
+        g.bn_part[1][o] = s;
+        g.bn_part[1][o + gCO] = q1;
+      }
+    }
   }
   if (part) {  // fused BatchNorm statistics: per-tile column sum / sum of squares, fp64 [tiles][2][C]
     double* redd = reinterpret_cast<double*>(red);           // WM * 2 * BN doubles <= 8 KB of the (free) operand LDS
@@ -253,6 +325,20 @@ static inline void make_dgrad_geom(IGemmGeom& g, int py, int px, int N, int H, i
   g.T = T; g.K = T * Cout;
   g.x_bytes = (unsigned)((size_t)N * OH * OW * Cout * 4);
   g.w_bytes = (unsigned)((size_t)KH * KW * Cin * Cout * 4);
+}
+
+// BatchNorm-backward reductions fused into an input-gradient launch (IGemmGeom::bn_x): validate the requests, attach them
+static inline int attach_bn_reqs(const char* who, IGemmGeom& g, const mla_bn_reduce_req* reqs, int nreq, int tile0) {
+  MLA_REQUIRE(nreq >= 0 && nreq <= 2 && (nreq == 0 || reqs), "%s: 0..2 BatchNorm reduction requests", who);
+  for (int q = 0; q < nreq; ++q) {
+    MLA_REQUIRE(reqs[q].x && reqs[q].mean && reqs[q].invstd && reqs[q].partial, "%s: null pointer in BatchNorm request %d", who, q);
+    g.bn_x[q] = reqs[q].x;
+    g.bn_mean[q] = reqs[q].mean;
+    g.bn_invstd[q] = reqs[q].invstd;
+    g.bn_part[q] = reqs[q].partial;
+  }
+  g.bn_tile0 = tile0;
+  return MLA_OK;
 }
 
 // Linear layers as 1-tap gather-GEMMs over token rows (see the Linear entry points in conv_igemm.hip)

@@ -38,6 +38,9 @@ PROTOTYPES = {
     "mla_conv2d_wsplit_batch": (_I, [_P, _P, _P, _I, _I, _P]),
     "mla_conv2d_fwd_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
     "mla_conv2d_dgrad_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P]),
+    "mla_conv2d_dgrad_bn_partial_elems": (_Z, [_I, _I, _I, _I]),
+    "mla_conv2d_dgrad_bn": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P, _I, _P, _P]),
+    "mla_conv2d_dgrad_split_bn": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _I, _P, _P]),
     "mla_conv2d_wgrad_split_ws_bytes": (_Z, [_I] * 9),
     "mla_conv2d_wgrad_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
     "mla_conv2d_split_terms": (_I, [_I]),
@@ -49,6 +52,7 @@ PROTOTYPES = {
     "mla_bn_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mla_bn_bwd_ws_elems": (_Z, [_I, _I]),
     "mla_bn_bwd": (_I, [_P] * 11 + [_I, _I, _P]),
+    "mla_bn_bwd_from_partial": (_I, [_P] * 9 + [_I, _I, _I, _P]),
     "mla_bn_relu_maxpool_fwd": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
     "mla_bn_bwd_pooled": (_I, [_P] * 11 + [_I, _I, _I, _I, _P]),
     "mla_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

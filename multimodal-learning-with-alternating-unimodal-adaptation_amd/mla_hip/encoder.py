@@ -33,6 +33,8 @@ from .module import BatchNorm2dHolder, Conv2dHolder, FlatModule
 # bf16 terms, six bf16 MFMAs per fp32 product, fp32 accumulate -- fp32 in / out, error against fp64 no larger than the fp32
 # MFMA's (tests/test_ops_gpu.py::test_conv_split_is_not_reduced_precision), 1.2-1.3x the throughput.  "f32" = v_mfma_f32_32x32x2_f32.
 DEFAULT_CONV_MATH = "split"
+# measurement switch (same-box A/B): 0 = every BatchNorm backward runs its own reduction pass (the round-1 / early round-2 flow)
+FUSE_BN_REDUCE = os.environ.get("MLA_FUSE_BN_REDUCE", "1") != "0"
 
 
 def conv_specs(modality: str) -> List[Tuple[str, int, int, int, int, int]]:
@@ -291,6 +293,10 @@ class ResNet18Encoder(FlatModule):
         ws["wgrad_ws"] = torch.empty((max_wgrad + 3) // 4, **f32)
         ws["wt_ws"] = torch.empty(max_w, **f32)
         ws["bn_ws"] = torch.empty(max_bnws, **f32)
+        # partial sums of the BatchNorm-backward reductions formed in input-gradient epilogues: block-below bn2, its downsample, bn1
+        n_bnp = max(ops.conv2d_dgrad_bn_partial_elems(b["out"].shape[0], b["out"].shape[1], b["out"].shape[2], b["cout"])
+                    for b in ws["blocks"])
+        ws["bnp"] = [torch.empty(n_bnp, **f32) for _ in range(3)]
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -420,10 +426,15 @@ class ResNet18Encoder(FlatModule):
     # ------------------------------------------------------------------------------------------
     # backward (explicit; fills self.grad completely)
     # ------------------------------------------------------------------------------------------
-    def _bn_bwd(self, ws, st, bn, dout, x, dx):
+    def _bn_bwd(self, ws, st, bn, dout, x, dx, reduced=None):
+        """reduced = (partial sums, tiles) when the producer of dout has already formed the reduction pass (_dgrad bn_next)."""
         C = self.bn_ch[bn]
         M = x.numel() // C
         mean, invstd = ws["stats"][bn]
+        if reduced is not None:
+            ops.bn_bwd_from_partial(dout, x, mean, invstd, self.p[bn + ".weight"], dx, self.g[bn + ".weight"],
+                                    self.g[bn + ".bias"], reduced[0], reduced[1], M, C, stream=st)
+            return
         ops.bn_bwd(dout, x, mean, invstd, self.p[bn + ".weight"], dx, self.g[bn + ".weight"], self.g[bn + ".bias"],
                    ws["bn_ws"], M, C, stream=st)
 
@@ -453,44 +464,66 @@ class ResNet18Encoder(FlatModule):
         with torch.cuda.stream(side):
             wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
 
-    def _dgrad(self, ws, st, dy, name, x_shape, stride, pad, dx, residual=None, relu_src=None) -> None:
+    def _dgrad(self, ws, st, dy, name, x_shape, stride, pad, dx, residual=None, relu_src=None, bn_next=()):
+        """Input gradient of conv `name`.  bn_next: [(bn name, its input y, partial buffer)] -- the BatchNorm layers whose
+        backward consumes dx: the epilogue forms their reduction pass; returns {bn name: (partial, tiles)}."""
         wsp = self.wsp.get(name)
         w = self.p[name + ".weight"]
+        if not FUSE_BN_REDUCE:
+            bn_next = ()
+        reqs = [(y,) + tuple(ws["stats"][bn]) + (part,) for bn, y, part in bn_next]
         if wsp is not None:
-            ops.conv2d_dgrad_split(dy, wsp[1], w.shape, x_shape, stride, pad, dx=dx, residual=residual, relu_src=relu_src,
-                                   stream=st)
+            r = ops.conv2d_dgrad_split(dy, wsp[1], w.shape, x_shape, stride, pad, dx=dx, residual=residual, relu_src=relu_src,
+                                       stream=st, bn_reqs=reqs)
         else:
-            ops.conv2d_dgrad(dy, w, x_shape, stride, pad, ws["wt_ws"], dx=dx, residual=residual, relu_src=relu_src, stream=st)
+            r = ops.conv2d_dgrad(dy, w, x_shape, stride, pad, ws["wt_ws"], dx=dx, residual=residual, relu_src=relu_src, stream=st,
+                                 bn_reqs=reqs)
+        return {bn: (part, r[1]) for bn, _, part in bn_next} if bn_next else {}
 
     def _backward_trunk(self, ws, st) -> None:
         """Expects G[0] = gradient w.r.t. the last block's output, already masked by (out > 0)."""
         G, DY = ws["G"], ws["DY"]
         if self.wgrad_stream is not None:
             self.wgrad_stream.wait_stream(torch.cuda.current_stream())      # wgrad_ws / grads of the previous step are consumed
-        for bi_, blk in reversed(list(enumerate(ws["blocks"]))):
+        # The reduction pass of a BatchNorm backward (sum g, sum g * xhat) is formed by the epilogue of the input-gradient kernel
+        # that writes g, for every BatchNorm but the last block's bn2 / downsample (g comes from the average pool) and the stem's:
+        # `have` = {bn name: (partial sums, tiles)} handed from the producing launch to the consuming BatchNorm backward.
+        blocks = ws["blocks"]
+        bnp = ws["bnp"]
+        have: dict = {}
+        for bi_, blk in reversed(list(enumerate(blocks))):
             pre = blk["pre"]
             oshape = blk["out"].shape
             n_out = blk["out"].numel()
             xin = blk["xin"]
             d = G[0][:n_out].view(oshape)
             dy2 = DY[pre + ".conv2"]
-            self._bn_bwd(ws, st, pre + ".bn2", d, blk["y2"], dy2)
+            self._bn_bwd(ws, st, pre + ".bn2", d, blk["y2"], dy2, have.pop(pre + ".bn2", None))
             self._wgrad(ws, blk["a1"], dy2, pre + ".conv2", 1, 1)
             da1 = G[2][:n_out].view(oshape)
-            self._dgrad(ws, st, dy2, pre + ".conv2", oshape, 1, 1, da1, relu_src=blk["a1"])
+            got = self._dgrad(ws, st, dy2, pre + ".conv2", oshape, 1, 1, da1, relu_src=blk["a1"],
+                              bn_next=[(pre + ".bn1", blk["y1"], bnp[2])])
             dy1 = DY[pre + ".conv1"]
-            self._bn_bwd(ws, st, pre + ".bn1", da1, blk["y1"], dy1)
+            self._bn_bwd(ws, st, pre + ".bn1", da1, blk["y1"], dy1, got.get(pre + ".bn1"))
             self._wgrad(ws, xin, dy1, pre + ".conv1", blk["stride"], 1)
             dx = G[3][:xin.numel()].view(xin.shape)
             mask = xin if bi_ > 0 else None          # block input is a ReLU output except after the max-pool
+            nxt = []                                 # BatchNorms of the block below that consume dx
+            if bi_ > 0:
+                prev = blocks[bi_ - 1]
+                nxt.append((prev["pre"] + ".bn2", prev["y2"], bnp[0]))
+                if prev["ds"]:
+                    nxt.append((prev["pre"] + ".downsample.1", prev["yd"], bnp[1]))
             if blk["ds"]:
                 dyd = DY[pre + ".downsample.0"]
-                self._bn_bwd(ws, st, pre + ".downsample.1", d, blk["yd"], dyd)
+                self._bn_bwd(ws, st, pre + ".downsample.1", d, blk["yd"], dyd, have.pop(pre + ".downsample.1", None))
                 self._wgrad(ws, xin, dyd, pre + ".downsample.0", blk["stride"], 0)
                 self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx)
-                self._dgrad(ws, st, dyd, pre + ".downsample.0", xin.shape, blk["stride"], 0, dx, residual=dx, relu_src=mask)
+                have = self._dgrad(ws, st, dyd, pre + ".downsample.0", xin.shape, blk["stride"], 0, dx, residual=dx, relu_src=mask,
+                                   bn_next=nxt)
             else:
-                self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx, residual=d, relu_src=mask)
+                have = self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx, residual=d, relu_src=mask,
+                                   bn_next=nxt)
             G[0], G[3] = G[3], G[0]
         # stem: maxpool -> relu -> bn1 -> conv1
         dpool = G[0][:ws["p0"].numel()].view(ws["p0"].shape)

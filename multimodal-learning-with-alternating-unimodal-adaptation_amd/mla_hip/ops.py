@@ -121,21 +121,50 @@ def conv2d_fwd(x: torch.Tensor, w_hwio: torch.Tensor, stride: int, pad: int, y: 
     return y, tiles.value
 
 
+class _BnReduceReq(ctypes.Structure):     # include/mla_hip.h: mla_bn_reduce_req
+    _fields_ = [("x", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("partial", ctypes.c_void_p)]
+
+
+def conv2d_dgrad_bn_partial_elems(N: int, H: int, W: int, Cin: int) -> int:
+    return int(_lib.load().mla_conv2d_dgrad_bn_partial_elems(N, H, W, Cin))
+
+
+def _bn_reqs(bn_reqs, x_shape):
+    """bn_reqs: sequence of (x, mean, invstd, partial) -- BatchNorm layers whose backward consumes dx (<= 2)."""
+    if not bn_reqs:
+        return None, 0
+    if len(bn_reqs) > 2:
+        raise MLAHipError("conv2d_dgrad: at most two BatchNorm reduction requests")
+    N, H, W, Cin = x_shape
+    need = conv2d_dgrad_bn_partial_elems(N, H, W, Cin)
+    arr = (_BnReduceReq * len(bn_reqs))()
+    for q, (x, mean, invstd, partial) in enumerate(bn_reqs):
+        if tuple(x.shape) != tuple(x_shape) or mean.numel() != Cin or invstd.numel() != Cin or partial.numel() < need:
+            raise MLAHipError(f"conv2d_dgrad: BatchNorm request {q} does not match dx {tuple(x_shape)} (partial >= {need} floats)")
+        arr[q].x, arr[q].mean, arr[q].invstd, arr[q].partial = _p(x), _p(mean), _p(invstd), _p(partial)
+    return arr, len(bn_reqs)
+
+
 def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_shape, stride: int, pad: int, wt_ws: torch.Tensor,
                  dx: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
+                 relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None, bn_reqs=None):
+    """Input gradient.  With bn_reqs (see _bn_reqs) the epilogue also forms the reduction pass of those BatchNorm
+    backwards and the call returns (dx, tiles) for bn_bwd_from_partial."""
     N, H, W, Cin = x_shape
     KH, KW, _, Cout = w_hwio.shape
     if dx is None:
         dx = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
     if wt_ws.numel() < w_hwio.numel():
         raise MLAHipError("conv2d_dgrad: wt_ws too small")
+    arr, nreq = _bn_reqs(bn_reqs, x_shape)
+    tiles = ctypes.c_int(0)
     t0 = TIMER.begin() if TIMER is not None else None
-    check(_lib.load().mla_conv2d_dgrad(_p(dy), _p(w_hwio), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                       _p(residual), _p(relu_src), _p(wt_ws), stream or cur_stream()), "mla_conv2d_dgrad")
+    check(_lib.load().mla_conv2d_dgrad_bn(_p(dy), _p(w_hwio), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                          _p(residual), _p(relu_src), _p(wt_ws), ctypes.addressof(arr) if nreq else None, nreq,
+                                          ctypes.addressof(tiles), stream or cur_stream()), "mla_conv2d_dgrad_bn")
     if t0 is not None:
         TIMER.end("conv_dgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
-    return dx
+    return (dx, tiles.value) if nreq else dx
 
 
 def conv2d_wsplit(w_hwio: torch.Tensor, transposed: bool, out: Optional[torch.Tensor] = None,
@@ -183,19 +212,22 @@ def conv2d_fwd_split(x: torch.Tensor, wsplit_t: torch.Tensor, w_shape, stride: i
 
 def conv2d_dgrad_split(dy: torch.Tensor, wsplit: torch.Tensor, w_shape, x_shape, stride: int, pad: int,
                        dx: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                       relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> torch.Tensor:
-    """conv2d_dgrad on the split-bf16 MFMA path; `wsplit` = conv2d_wsplit(w, False)."""
+                       relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None, bn_reqs=None):
+    """conv2d_dgrad on the split-bf16 MFMA path; `wsplit` = conv2d_wsplit(w, False).  bn_reqs as in conv2d_dgrad."""
     N, H, W, Cin = x_shape
     KH, KW, _, Cout = w_shape
     if dx is None:
         dx = torch.empty((N, H, W, Cin), device=dy.device, dtype=torch.float32)
+    arr, nreq = _bn_reqs(bn_reqs, x_shape)
+    tiles = ctypes.c_int(0)
     t0 = TIMER.begin() if TIMER is not None else None
-    check(_lib.load().mla_conv2d_dgrad_split(_p(dy), _p(wsplit, torch.int16), _p(dx), N, H, W, Cin, Cout, KH, KW, stride,
-                                             pad, _p(residual), _p(relu_src), stream or cur_stream()),
-          "mla_conv2d_dgrad_split")
+    check(_lib.load().mla_conv2d_dgrad_split_bn(_p(dy), _p(wsplit, torch.int16), _p(dx), N, H, W, Cin, Cout, KH, KW, stride,
+                                                pad, _p(residual), _p(relu_src), ctypes.addressof(arr) if nreq else None, nreq,
+                                                ctypes.addressof(tiles), stream or cur_stream()),
+          "mla_conv2d_dgrad_split_bn")
     if t0 is not None:
         TIMER.end("conv_dgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
-    return dx
+    return (dx, tiles.value) if nreq else dx
 
 
 def conv2d_split_terms(terms: int = 0) -> int:
@@ -309,6 +341,16 @@ def bn_bwd_pooled(dpool, idx, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, w
     if t0 is not None:   # y twice, dy once, the pooled gradient + index twice
         by = 12.0 * N * H * W * C + 10.0 * dpool.numel()
         TIMER.end("bn_bwd_pooled", by, t0, moved=by)
+
+
+def bn_bwd_from_partial(dout, x, mean, invstd, gamma, dx, dgamma, dbeta, partial, tiles: int, M: int, C: int,
+                        stream: Optional[int] = None) -> None:
+    """BatchNorm backward whose reduction pass was formed by the input-gradient kernel that wrote `dout` (bn_reqs)."""
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_bn_bwd_from_partial(_p(dout), _p(x), _p(mean), _p(invstd), _p(gamma), _p(dx), _p(dgamma), _p(dbeta),
+                                              _p(partial), tiles, M, C, stream or cur_stream()), "mla_bn_bwd_from_partial")
+    if t0 is not None:   # dy, x read once; dx written
+        TIMER.end("bn_bwd", 12.0 * M * C, t0, moved=12.0 * M * C)
 
 
 # ---- pooling ------------------------------------------------------------------------------------

@@ -156,6 +156,67 @@ def test_wsplit_batch_matches_per_conv(ops):
         assert torch.equal(planes.sum(0), w), name          # exact 3-way split (sum of three bf16 values in fp32)
 
 
+@pytest.mark.parametrize("math_", ["f32", "split"])
+@pytest.mark.parametrize("case", [c for c in SPLIT_CASES if c[5] in (1, 3)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_dgrad_fused_bn_reduction(ops, case, math_):
+    """mla_conv2d_dgrad[_split]_bn: the input-gradient epilogue also forms the reduction pass (sum g, sum g * xhat per tile) of
+    up to two BatchNorm backwards that consume its output.  Against (1) the stand-alone BatchNorm backward on the same dx
+    (dgamma, dbeta, dx': same formula, different summation order) and (2) the oracle's BatchNorm backward."""
+    N, H, W, Cin, Cout, k, s, p = case
+    seed = sum(case) + 7
+    x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
+    w = O.portable_normal(seed, (Cout, Cin, k, k), stream=2, std=math.sqrt(2.0 / (Cin * k * k)))
+    y_ref = O.conv2d_fwd(x, w, s, p)
+    dy = O.portable_normal(seed, tuple(y_ref.shape), stream=3)
+    res = O.portable_normal(seed, (N, Cin, H, W), stream=4)
+    msk = O.portable_normal(seed, (N, Cin, H, W), stream=5)
+    wd, dyd = hwio(w).cuda(), nhwc(dy).cuda()
+    M = N * H * W
+    # two BatchNorm layers (inputs z0, z1: any tensors of dx's shape with their batch statistics)
+    zs = [nhwc(O.portable_normal(seed, (N, Cin, H, W), stream=6 + q, mean=0.3 * q, std=1.0 + q)).cuda() for q in range(2)]
+    stats = []
+    for z in zs:
+        part = torch.empty(ops.bn_stats_partial_elems(M, Cin), device="cuda")
+        tiles = ops.bn_stats_partial(z.view(M, Cin), M, Cin, part)
+        mean, invstd = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+        ops.bn_finalize(part, tiles, M, Cin, mean, invstd, None, None)
+        stats.append((mean, invstd))
+    gamma = O.portable_normal(seed, (Cin,), stream=9, mean=1.0, std=0.2).cuda()
+    need = ops.conv2d_dgrad_bn_partial_elems(N, H, W, Cin)
+    for nreq in (1, 2):
+        parts = [torch.full((need,), float("nan"), device="cuda") for _ in range(nreq)]
+        reqs = [(zs[q],) + stats[q] + (parts[q],) for q in range(nreq)]
+        dx = torch.empty((N, H, W, Cin), device="cuda")
+        kw = dict(dx=dx, residual=nhwc(res).cuda(), relu_src=nhwc(msk).cuda(), bn_reqs=reqs)
+        if math_ == "split":
+            _, tiles = ops.conv2d_dgrad_split(dyd, ops.conv2d_wsplit(wd, False), wd.shape, (N, H, W, Cin), s, p, **kw)
+            dx_plain = ops.conv2d_dgrad_split(dyd, ops.conv2d_wsplit(wd, False), wd.shape, (N, H, W, Cin), s, p,
+                                              residual=kw["residual"], relu_src=kw["relu_src"])
+        else:
+            wt_ws = torch.empty(wd.numel(), device="cuda")
+            _, tiles = ops.conv2d_dgrad(dyd, wd, (N, H, W, Cin), s, p, wt_ws, **kw)
+            dx_plain = ops.conv2d_dgrad(dyd, wd, (N, H, W, Cin), s, p, wt_ws, residual=kw["residual"], relu_src=kw["relu_src"])
+        assert torch.equal(dx, dx_plain), "the fused reductions must not change dx"
+        assert tiles >= 1
+        ws = torch.empty(ops.bn_bwd_ws_elems(M, Cin), device="cuda")
+        for q in range(nreq):
+            mean, invstd = stats[q]
+            o1, dg1, db1 = torch.empty_like(dx), torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+            ops.bn_bwd(dx.view(M, Cin), zs[q].view(M, Cin), mean, invstd, gamma, o1.view(M, Cin), dg1, db1, ws, M, Cin)
+            o2, dg2, db2 = torch.empty_like(dx), torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+            ops.bn_bwd_from_partial(dx.view(M, Cin), zs[q].view(M, Cin), mean, invstd, gamma, o2.view(M, Cin), dg2, db2, parts[q],
+                                    tiles, M, Cin)
+            sc_g, sc_b = dg1.abs().max().item(), db1.abs().max().item()
+            assert_close(dg2, dg1, atol=2e-6 * sc_g, name=f"fused dgamma (req {q})")
+            assert_close(db2, db1, atol=2e-6 * sc_b, name=f"fused dbeta (req {q})")
+            assert_close(o2, o1, atol=2e-6 * o1.abs().max().item(), name=f"fused BN dx (req {q})")
+            g_ref = nchw(dx.cpu())
+            dx_ref, dgamma_ref, dbeta_ref = O.bn_train_bwd(g_ref, nchw(zs[q].cpu()), gamma.cpu(), mean.cpu(), invstd.cpu())
+            assert_close(dg2, dgamma_ref, atol=1e-4, rtol=5e-5, name=f"fused dgamma vs oracle (req {q})")
+            assert_close(db2, dbeta_ref, atol=1e-4, rtol=5e-5, name=f"fused dbeta vs oracle (req {q})")
+            assert_close(nchw(o2.cpu()), dx_ref, atol=2e-6 * max(1.0, dx_ref.abs().max().item()), rtol=5e-5, name=f"fused BN dx vs oracle (req {q})")
+
+
 def test_conv_split_is_not_reduced_precision(ops):
     """The claim behind conv_math="split": against an fp64 reference the six-product bf16 split is at least as
     accurate as the exact-fp32 MFMA kernel (same inputs, K = 576 .. 4608), element-wise maximum and rms.  The
