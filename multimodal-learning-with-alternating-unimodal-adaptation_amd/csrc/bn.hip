@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
 //   forward   mla_bn_relu_maxpool_fwd: the max-pool reads y (the conv output) and applies BN + ReLU on the fly
 //             (saves writing and re-reading a_stem: 2.3 GB per step);
 //   backward  mla_bn_bwd_pooled: the BatchNorm backward takes its upstream gradient straight from the POOLED gradient --
-//             g[pixel] = [bn(y) > 0] * sum over the <= 4 windows that selected this pixel -- in both its reduction and its
-//             apply pass (saves writing and twice re-reading the scattered gradient and reading a_stem: 4.2 GB per step).
+//             g[pixel] = [bn(y) > 0] * sum over the <= 4 windows that selected this pixel -- in its reduction pass (as a sum
+//             over pooled outputs) and in its apply pass (saves writing and twice re-reading the scattered gradient and reading a_stem: 4.2 GB per step).
 // bn_val (above) is the one expression both directions use, so the recomputed ReLU mask and the max-pool decisions agree
 // bit for bit.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -389,26 +389,69 @@ __device__ __forceinline__ f32x4 pooled_grad(const float* __restrict__ dpool, co
   return acc;
 }
 
-// PASS 0: per-tile (sum g, sum g * xhat) partials (layout of bn_reduce_kernel<1>);  PASS 1: dy = gamma * invstd * (g - db/M - xhat * dg/M)
-template <int PASS>
-__global__ __launch_bounds__(256) void bn_bwd_pooled_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
-                                                             const float* __restrict__ y, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ dgamma,
-                                                             const float* __restrict__ dbeta, float* __restrict__ out, int N, int H,
-                                                             int W, int C, int OH, int OW, int tile_rows) {
+// The reduction pass in scatter form: sum_pixels g = sum over POOLED outputs o of dpool[o] * [bn(y[sel(o)]) > 0] (every pooled output
+// selected exactly one pixel per channel), likewise sum g * xhat -- a quarter of the iterations of the per-pixel gather form and
+// 6 loads per thread instead of 9.  Tiles are rows of pooled pixels; partial layout as bn_reduce_kernel<1>.
+__global__ __launch_bounds__(256) void bn_bwd_pooled_reduce_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                    const float* __restrict__ y, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ out, int N, int H,
+                                                                    int W, int C, int OH, int OW, int tile_rows) {
   __shared__ f32x4 red[2][256];
+  const int c4n = C >> 2, MP = N * OH * OW;
+  const int cg = threadIdx.x % c4n, rl = threadIdx.x / c4n, nrl = 256 / c4n;
+  const int r0 = blockIdx.x * tile_rows, r1 = min(MP, r0 + tile_rows);
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
+  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + rl; r < r1; r += nrl) {
+    const int ox = r % OW, t = r / OW, oy = t % OH, n = t / OH;
+    const size_t o = (size_t)r * c4n + cg;
+    const f32x4 g = reinterpret_cast<const f32x4*>(dpool)[o];
+    const uchar4 sel = reinterpret_cast<const uchar4*>(idx)[o];
+    const int code[4] = {sel.x, sel.y, sel.z, sel.w};
+    f32x4 xv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kh = (code[e] * 11) >> 5, kw = code[e] - 3 * kh;      // code = kh * 3 + kw, 0..8
+      xv[e] = y[((size_t)(n * H + oy * 2 - 1 + kh) * W + (ox * 2 - 1 + kw)) * C + cg * 4 + e];
+    }
+    const f32x4 a = bn_val(xv, mu, is, ga, be);
+    const f32x4 xhat = (xv - mu) * is;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = a[e] > 0.f ? g[e] : 0.f;
+      s0[e] += ge;
+      s1[e] += ge * xhat[e];
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < nrl; ++k) {
+      s0 += red[0][k * c4n + cg];
+      s1 += red[1][k * c4n + cg];
+    }
+    reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.x * 2 + 0) * C)[cg] = s0;
+    reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.x * 2 + 1) * C)[cg] = s1;
+  }
+}
+
+// The apply pass: dy = gamma * invstd * (g - db/M - xhat * dg/M), g gathered per pixel from the <= 4 windows that may have selected it
+__global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                   const float* __restrict__ y, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                                                   const float* __restrict__ dbeta, float* __restrict__ out, int N, int H,
+                                                                   int W, int C, int OH, int OW, int tile_rows) {
   const int c4n = C >> 2, M = N * H * W;
   const int cg = threadIdx.x % c4n, rl = threadIdx.x / c4n, nrl = 256 / c4n;
   const int r0 = blockIdx.x * tile_rows, r1 = min(M, r0 + tile_rows);
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
   const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, dg = s0, db = s0;
-  if (PASS == 1) {
-    const float invM = 1.0f / (float)M;
-    dg = reinterpret_cast<const f32x4*>(dgamma)[cg] * invM;
-    db = reinterpret_cast<const f32x4*>(dbeta)[cg] * invM;
-  }
+  const float invM = 1.0f / (float)M;
+  const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[cg] * invM, db = reinterpret_cast<const f32x4*>(dbeta)[cg] * invM;
   for (int r = r0 + rl; r < r1; r += nrl) {
     const int ix = r % W, t = r / W, iy = t % H, n = t / H;
     const size_t i = (size_t)r * c4n + cg;
@@ -418,25 +461,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
     const f32x4 xhat = (xv - mu) * is;
-    if (PASS == 0) {
-      s0 += g;
-      s1 += g * xhat;
-    } else {
-      reinterpret_cast<f32x4*>(out)[i] = ga * is * (g - db - xhat * dg);
-    }
-  }
-  if (PASS == 0) {
-    red[0][threadIdx.x] = s0;
-    red[1][threadIdx.x] = s1;
-    __syncthreads();
-    if (rl == 0) {
-      for (int k = 1; k < nrl; ++k) {
-        s0 += red[0][k * c4n + cg];
-        s1 += red[1][k * c4n + cg];
-      }
-      reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.x * 2 + 0) * C)[cg] = s0;
-      reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.x * 2 + 1) * C)[cg] = s1;
-    }
+    reinterpret_cast<f32x4*>(out)[i] = ga * is * (g - db - xhat * dg);
   }
 }
 
@@ -568,9 +593,10 @@ extern "C" int mla_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const f
   MLA_REQUIRE(dpool && idx && y && mean && invstd && gamma && beta && dy && dgamma && dbeta && ws, "mla_bn_bwd_pooled: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  const int tr = bn_tile_rows(M), nt = cdiv(M, tr);
-  bn_bwd_pooled_kernel<0><<<nt, 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, nullptr, nullptr, ws, N, H, W, C, OH, OW, tr);
-  MLA_CHECK_LAUNCH("bn_bwd_pooled_kernel<0>");
+  const int MP = N * OH * OW;
+  const int trp = bn_tile_rows(MP), nt = cdiv(MP, trp);     // reduction: tiles of pooled pixels (<= the tiles of M the workspace holds)
+  bn_bwd_pooled_reduce_kernel<<<nt, 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, ws, N, H, W, C, OH, OW, trp);
+  MLA_CHECK_LAUNCH("bn_bwd_pooled_reduce_kernel");
   if (nt <= BN_ONE_MAXT) {
     bn_finalize_tiles_kernel<float, 0><<<cdiv(C, 16), 256, 0, st>>>(ws, nt, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
     MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
@@ -582,8 +608,8 @@ extern "C" int mla_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const f
     bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
     MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   }
-  // the apply pass walks the same row tiles (a tile's pooled-gradient reads are then L2 hits of its own first pass)
-  bn_bwd_pooled_kernel<1><<<nt, 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, N, H, W, C, OH, OW, tr);
-  MLA_CHECK_LAUNCH("bn_bwd_pooled_kernel<1>");
+  const int tr = bn_tile_rows(M);
+  bn_bwd_pooled_apply_kernel<<<cdiv(M, tr), 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, N, H, W, C, OH, OW, tr);
+  MLA_CHECK_LAUNCH("bn_bwd_pooled_apply_kernel");
   return MLA_OK;
 }

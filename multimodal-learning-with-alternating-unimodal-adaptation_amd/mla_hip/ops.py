@@ -328,7 +328,7 @@ def bn_relu_maxpool_fwd(y, mean, invstd, gamma, beta, out, idx, stream: Optional
           "mla_bn_relu_maxpool_fwd")
     if t0 is not None:   # read y once, write the pooled quarter + its index bytes
         by = 4.0 * N * H * W * C + 5.0 * out.numel()
-        TIMER.end("bn_relu_maxpool_fwd", by, t0, moved=by)
+        TIMER.end("bn_fwd", by, t0, moved=by)
 
 
 def bn_bwd_pooled(dpool, idx, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, ws, stream: Optional[int] = None) -> None:
@@ -340,7 +340,7 @@ def bn_bwd_pooled(dpool, idx, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, w
           "mla_bn_bwd_pooled")
     if t0 is not None:   # y twice, dy once, the pooled gradient + index twice
         by = 12.0 * N * H * W * C + 10.0 * dpool.numel()
-        TIMER.end("bn_bwd_pooled", by, t0, moved=by)
+        TIMER.end("bn_bwd", by, t0, moved=by)
 
 
 def bn_bwd_from_partial(dout, x, mean, invstd, gamma, dx, dgamma, dbeta, partial, tiles: int, M: int, C: int,
