@@ -270,6 +270,7 @@ def main() -> None:
                          "frac": round(achieved / peak, 4), "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": traffic,
                          "avg_launch_ms": round(ig["ms"] / max(ig["launches"], 1), 4),
+                         "stalled_brackets_replaced_by_median": sum(v.get("stalls", 0) for v in summ.values()),
                          "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2),
                          "measured": "HIP events around every conv launch over %d steps run right after the timed region "
                                      "with the stream pipeline off (serialized, event-instrumented: %.3f ms/step); in the timed "

@@ -110,6 +110,29 @@ def maxpool3x3s2_bwd(dy, idx, x_shape, relu_src=None):
     return dx
 
 
+@_op("conv2d_dgrad_bn(Tensor dy, Tensor w_hwio, int[] x_shape, int stride, int pad, Tensor bn_x, Tensor bn_mean, Tensor bn_invstd, "
+     "Tensor? residual=None, Tensor? relu_src=None) -> (Tensor, Tensor, int)")
+def conv2d_dgrad_bn(dy, w_hwio, x_shape, stride, pad, bn_x, bn_mean, bn_invstd, residual=None, relu_src=None):
+    """Input gradient whose epilogue also forms the reduction pass of the BatchNorm backward that consumes dx
+    (bn_x = that BatchNorm's input): returns (dx, partial sums, tiles) for bn_bwd_from_partial."""
+    N, H, W, Cin = x_shape
+    wt_ws = _f32((w_hwio.numel(),), dy)
+    part = _f32((ops.conv2d_dgrad_bn_partial_elems(N, H, W, Cin),), dy)
+    dx, tiles = ops.conv2d_dgrad(dy, w_hwio, tuple(x_shape), stride, pad, wt_ws, residual=residual, relu_src=relu_src,
+                                 bn_reqs=[(bn_x, bn_mean, bn_invstd, part)])
+    return dx, part, tiles
+
+
+@_op("bn_bwd_from_partial(Tensor dout, Tensor x, Tensor mean, Tensor invstd, Tensor gamma, Tensor partial, int tiles) -> (Tensor, Tensor, Tensor)")
+def bn_bwd_from_partial(dout, x, mean, invstd, gamma, partial, tiles):
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    dg, db = _f32((C,), x), _f32((C,), x)
+    ops.bn_bwd_from_partial(dout, x, mean, invstd, gamma, dx, dg, db, partial, tiles, M, C)
+    return dx, dg, db
+
+
 @_op("bn_relu_maxpool_fwd(Tensor y, Tensor mean, Tensor invstd, Tensor gamma, Tensor beta) -> (Tensor, Tensor)")
 def bn_relu_maxpool_fwd(y, mean, invstd, gamma, beta):
     """maxpool3x3s2(relu(bn(y))) for the stem (backbone.py:150-152) without materialising the ReLU output."""

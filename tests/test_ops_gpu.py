@@ -215,6 +215,13 @@ def test_conv_dgrad_fused_bn_reduction(ops, case, math_):
             assert_close(dg2, dgamma_ref, atol=1e-4, rtol=5e-5, name=f"fused dgamma vs oracle (req {q})")
             assert_close(db2, dbeta_ref, atol=1e-4, rtol=5e-5, name=f"fused dbeta vs oracle (req {q})")
             assert_close(nchw(o2.cpu()), dx_ref, atol=2e-6 * max(1.0, dx_ref.abs().max().item()), rtol=5e-5, name=f"fused BN dx vs oracle (req {q})")
+    if math_ == "f32":      # the torch.ops face of the same pair
+        dx_t, part_t, tiles_t = torch.ops.mla_hip.conv2d_dgrad_bn(dyd, wd, [N, H, W, Cin], s, p, zs[0], stats[0][0], stats[0][1],
+                                                                  nhwc(res).cuda(), nhwc(msk).cuda())
+        o_t, dg_t, db_t = torch.ops.mla_hip.bn_bwd_from_partial(dx_t, zs[0], stats[0][0], stats[0][1], gamma, part_t, tiles_t)
+        assert torch.equal(dx_t, dx) and tiles_t == tiles
+        ops.bn_bwd_from_partial(dx.view(M, Cin), zs[0].view(M, Cin), stats[0][0], stats[0][1], gamma, o2.view(M, Cin), dg2, db2, parts[0], tiles, M, Cin)
+        assert torch.equal(o_t, o2) and torch.equal(dg_t, dg2) and torch.equal(db_t, db2)
 
 
 def test_conv_split_is_not_reduced_precision(ops):
