@@ -551,8 +551,11 @@ extern "C" int mla_conv2d_split_cfg(int cfg) { g_split_cfg = (cfg >= 0 && cfg < 
 // Minimise rounds * resident workgroups * tile area / efficiency.  Small tiles stage more bytes per MFMA.  The
 // efficiencies are the measured per-flop rates at the ResNet-18 layer shapes relative to the 256x128 tile
 // (scripts/split_probe.py); the ranking they give matches the measured ranking on l1..l4 of both modalities.
-static int pick_scfg(long M, int CO, int weight) {
+static int pick_scfg(long M, int CO, int weight, int k_total = 1 << 30) {
   if (g_split_cfg >= 0 && CO % scfg_bn(g_split_cfg) == 0) return g_split_cfg;
+  // one-tap convolutions with a short K (the 1x1 stride-2 downsample convs, K <= 512: 2-16 stages per tile): prologue and epilogue
+  // dominate, the 64x64 tile with three workgroups per CU is fastest at every such shape (forced-tile probe, 10-45 % over the model)
+  if (k_total <= 512 && M <= (1L << 18)) return SCFG_64x64;
   const double eff[SCFG_COUNT] = {SPLIT_EFF};
   const int per_cu_tab[SCFG_COUNT] = {1, 1, 2, 3, 2};            // resident workgroups per CU (LDS / VGPRs)
   int best = -1;
@@ -620,7 +623,7 @@ extern "C" int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float*
   IGemmGeom g;
   make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
   MLA_REQUIRE(g.OH > 0 && g.OW > 0, "mla_conv2d_fwd_split: empty output");
-  const int cfg = pick_scfg(g.M, Cout, 1);
+  const int cfg = pick_scfg(g.M, Cout, 1, KH * KW * Cin);
   if (bn_tiles) *bn_tiles = cdiv(g.M, scfg_bm(cfg));
   return launch_split(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, cfg, (hipStream_t)stream);
 }
@@ -643,7 +646,7 @@ extern "C" int mla_conv2d_dgrad_split_bn(const float* dy, const void* wsplit, fl
       IGemmGeom g;
       make_dgrad_geom(g, py, px, N, H, W, Cin, Cout, KH, KW, stride, pad);
       if (g.M <= 0) continue;
-      const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1);
+      const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1, KH * KW == 1 ? Cout : 1 << 30);
       if (int rc = attach_bn_reqs("mla_conv2d_dgrad_split_bn", g, reqs, nreq, tiles)) return rc;
       if (int rc = launch_split(dy, wsplit, dx, residual, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
       tiles += cdiv(g.M, scfg_bm(cfg));
