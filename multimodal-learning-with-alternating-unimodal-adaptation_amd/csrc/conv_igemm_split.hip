@@ -655,13 +655,26 @@ extern "C" int mla_conv2d_dgrad_split_bn(const float* dy, const void* wsplit, fl
   return MLA_OK;
 }
 
-// split-K plan of the split weight gradient: one 128x128 workgroup per CU (two 64x64), about two rounds of the chip
+// split-K plan of the split weight gradient: the number of pixel ranges that minimises  rounds x (pixels per range + c0),
+// rounds = ceil(workgroups / resident slots) (one 128x128 workgroup per CU, two 64x64), c0 = the fixed cost of a workgroup
+// (prologue, slab write, its share of the ordered reduce) in pixel-equivalents.  Calibrated on a same-box sweep of the split
+// count at the ResNet-18 shapes: layer2 / layer3 (9 / 36 tiles) want ONE round of ~252 workgroups (-3 % against two), layer4
+// (144 tiles) wants 5 ranges = 2.8 rounds (-5 % against 3 ranges = 1.7 rounds), the 64x64 layers two full rounds of 512.
 static void wgrad_split_plan(long M, int Cin, int Cout, int T, int* span, int* splits) {
   const int BI = (Cin % 128 == 0 && Cout % 128 == 0) ? 128 : 64;
   const long tiles = (long)(Cin / BI) * T * (Cout / BI);
-  long want = (BI == 64 ? 1024 : 512) / tiles;
-  if (want < 1) want = 1;
-  long s = (M + want - 1) / want;
+  const long slots = BI == 64 ? 512 : 256;
+  const double c0 = 250.0;
+  long best_s = 1;
+  double best_cost = 0;
+  const long smax = M / 256 > 1 ? (M / 256 < 512 ? M / 256 : 512) : 1;
+  for (long sp = 1; sp <= smax; ++sp) {
+    const long rounds = (tiles * sp + slots - 1) / slots;
+    if (rounds > 4) break;                                   // more rounds only add slabs to reduce
+    const double cost = (double)rounds * ((double)((M + sp - 1) / sp) + c0);
+    if (sp == 1 || cost < best_cost * 0.995) { best_s = sp; best_cost = cost; }
+  }
+  long s = (M + best_s - 1) / best_s;
   s = ((s + BK - 1) / BK) * BK;
   if (s < 256) s = 256;
   *span = (int)s;
