@@ -508,7 +508,8 @@ static void wgrad_plan(long M, int Cin, int Cout, int T, int* span, int* splits)
   const long tiles = (long)(scalar ? cdiv((long)T * Cin, BI) : (Cin / BI) * T) * (Cout / BJ);
   // workgroup budget: 3 rounds of 256 for the 128x128 tile (134 VGPRs: 3 resident per CU), 8 rounds for the
   // 64x64 tile (60 VGPRs).  Measured on the layer shapes: 64x64 layers gain 4-8 % from 768 -> 2048.
-  long want = (BI == 64 ? 2048 : 768) / tiles;
+  // stem (scalar gathers, 60 VGPRs: 6 workgroups per CU): one round of 1536 (-4 % against 2048 = 1.33 rounds, same-box sweep)
+  long want = (scalar ? 1536 : (BI == 64 ? 2048 : 768)) / tiles;
   if (want < 1) want = 1;
   long s = (M + want - 1) / want;
   s = ((s + BK - 1) / BK) * BK;                  // whole K steps; spans longer than WG_CHUNK are walked in sub-chunks
