@@ -36,7 +36,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // low hal
 }
 // a - b as ONE v_sub_f32: the SLP vectoriser otherwise pairs the two residual subtractions of split_pair into v_pk_add_f32,
 // which costs more issue time beside MFMAs than the two scalar subtractions it replaces (gather-GEMM forward / input gradient:
-// -0.5...1 % time in a same-box A/B; the weight-gradient kernels keep the compiler's choice)
+// -0.5...1 % time in a same-box A/B; weight gradient -3.5 %: there the packing even needs v_mov pairs to line the registers up.
+// Residuals by v_dot2c_f32_bf16 (one instruction instead of expand + subtract) measured +4...6 % slower and not bit-identical)
 __device__ __forceinline__ float sub_scalar(float a, float b) {
   float r;
   asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -409,14 +410,14 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_split_kernel(const floa
         unsigned* dst = base + e * LROW;
         if constexpr (PX == 4) {
           unsigned h0, m0, l0, h1, m1, l1;
-          split_pair(reg[0][e], reg[1][e], h0, m0, l0);
-          split_pair(reg[2][e], reg[3][e], h1, m1, l1);
+          split_pair<true>(reg[0][e], reg[1][e], h0, m0, l0);
+          split_pair<true>(reg[2][e], reg[3][e], h1, m1, l1);
           *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
           *reinterpret_cast<u32x2*>(dst + plane_rows * LROW) = u32x2{m0, m1};
           *reinterpret_cast<u32x2*>(dst + 2 * plane_rows * LROW) = u32x2{l0, l1};
         } else {
           unsigned h0, m0, l0;
-          split_pair(reg[0][e], reg[1][e], h0, m0, l0);
+          split_pair<true>(reg[0][e], reg[1][e], h0, m0, l0);
           dst[0] = h0;
           dst[plane_rows * LROW] = m0;
           dst[2 * plane_rows * LROW] = l0;
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_split_kernel(const floa
     if (nIter > 1) load_tiles(BK);
     __syncthreads();
     int it = 0;
-    for (; it + 2 < nIter; ++it) {   // branch-free steady state (see igemm_split_kernel)
+    for (; it + 2 < nIter; ++it) {   // branch-free steady state (see igemm_split_kernel); unrolling by two with compile-time
+                                     // LDS buffers (address arithmetic folded into offset fields) measured +0.5 % slower
       const int cur = it & 1;
       load_frags(cur, 0, f0);
       load_frags(cur, 1, f1);
