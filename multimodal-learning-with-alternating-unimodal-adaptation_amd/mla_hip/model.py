@@ -14,6 +14,8 @@ import math
 from typing import Dict, Optional
 
 import torch
+
+from .streams import distinct_streams
 import torch.nn as nn
 
 from . import ops
@@ -102,6 +104,13 @@ class _Classifier(nn.Module):
         """`model.module.fusion_module.fc_out` (main.py:432) also works on the bare model (no DataParallel wrapper)."""
         return self
 
+    def _side_stream(self) -> torch.cuda.Stream:
+        """One weight-gradient side stream for all encoders of this model on the protocol path, on a hardware queue of its own
+        (streams.py): the encoders' backwards run one after the other there, so one stream serves them all."""
+        if getattr(self, "_wgrad_side", None) is None:
+            self._wgrad_side = distinct_streams(1, self.device)[0]
+        return self._wgrad_side
+
     def _feature(self, enc, run, B: int, D: int) -> torch.Tensor:
         if torch.is_grad_enabled() and self.training:
             if not hasattr(enc, "_anchor"):
@@ -109,7 +118,7 @@ class _Classifier(nn.Module):
                 # protocol path: the weight-gradient GEMMs of a backward run on a side stream beside the dgrad -> BN-backward
                 # chain (joined before the gradients are published), like in MLATrainer's pipeline
                 if self.side_streams and getattr(enc, "wgrad_stream", 0) is None and self.device.type == "cuda":
-                    enc.wgrad_stream = torch.cuda.Stream(device=self.device)
+                    enc.wgrad_stream = self._side_stream()
             return EncoderFeature.apply(enc._anchor, enc, run, B, D)
         out = torch.empty((B, D), device=self.device, dtype=torch.float32)
         run(out)

@@ -19,6 +19,8 @@ from typing import Optional
 
 import torch
 
+from .streams import distinct_streams
+
 from . import ops
 from .dist import Comm
 from .optim import FusedSGD
@@ -53,8 +55,11 @@ class MLATrainer:
         # chains run beside each other and across step boundaries (the last modality's backward overlaps the next
         # step's first forward) and fill each other's kernel tails.
         self._can_overlap = dev.type == "cuda" and hasattr(model, "forward_split")
-        self._estreams = [torch.cuda.Stream(device=dev) for _ in self.encoders] if self._can_overlap else []
-        self._wstreams = [torch.cuda.Stream(device=dev) for _ in self.encoders] if self._can_overlap else []
+        # encoder chains first (they must not share a hardware queue with each other or with the caller's stream), then the
+        # weight-gradient side streams, which may double up when the queues run out (streams.py)
+        ne = len(self.encoders)
+        pool = distinct_streams(2 * ne, dev) if self._can_overlap else []
+        self._estreams, self._wstreams = pool[:ne], pool[ne:]
         self.overlap_forward = False
         self.set_overlap(self._can_overlap)
 

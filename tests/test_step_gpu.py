@@ -435,3 +435,27 @@ def test_training_learns_a_synthetic_task():
     assert (tail < 0.6 * head).all(), (head, tail)
     assert tr.gs_plugin.exp_count == 2 * steps and not torch.equal(tr.gs_plugin.Pl.cpu(), torch.eye(512))
     assert torch.isfinite(model.audio_net.flat).all() and torch.isfinite(model.visual_net.flat).all()
+
+
+def test_streams_on_distinct_hardware_queues():
+    """mla_hip.streams: ROCm multiplexes HIP streams onto a few hardware queues and two streams on one queue serialise, so the
+    stream pipeline used to keep or lose its overlap with the number of streams the process had created before (two extra
+    streams: both encoder chains on one queue, +11 % step time).  distinct_streams measures the sharing with spin kernels: the
+    streams it hands out for the encoder chains must not serialise with each other nor with the current stream, whatever was
+    created first."""
+    from mla_hip import streams
+    dev = torch.device("cuda")
+    junk = [torch.cuda.Stream() for _ in range(2)]                 # what RCCL / a second model / a loader would do
+    for st in junk:
+        with torch.cuda.stream(st):
+            torch.zeros(16, device=dev).add_(1)
+    got = streams.distinct_streams(4, dev)
+    assert len(got) == 4
+    pool = streams._pools[torch.cuda.current_device()]
+    assert len(pool.classes) >= 3, "expected at least three hardware queues besides the caller's"
+    cur = torch.cuda.current_stream()
+    assert not pool.shares_queue(got[0], got[1]), "the two encoder-chain streams share a hardware queue"
+    assert not pool.shares_queue(cur, got[0]) and not pool.shares_queue(cur, got[1])
+    assert not pool.shares_queue(got[0], got[2]) and not pool.shares_queue(got[1], got[2])
+    again = streams.distinct_streams(2, dev)                        # drawn from the same pool
+    assert again[0] is got[0] and again[1] is got[1]
