@@ -23,6 +23,20 @@ import torch
 import torch.distributed as dist
 
 
+def _high_priority_options(group):
+    """RCCL communicator of the head exchange on a HIGH-PRIORITY stream: the 3.6 K-float message is on the step's critical path,
+    and priority streams get hardware queues of their own, so its kernel neither waits behind compute packets nor shares a
+    queue with an encoder chain (streams.py).  None (default options) for other backends or older torch."""
+    try:
+        if dist.get_backend(group) != "nccl":
+            return None
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:       # pragma: no cover - backend without options
+        return None
+
+
 class Comm:
     def __init__(self, group=None, bucket_bytes: int = 16 << 20, force: bool = False, dedicated_head_group: bool = True):
         """force=True issues every collective even with a single rank (used to rehearse the RCCL path on
@@ -37,7 +51,7 @@ class Comm:
         self.head_group = group
         if self.active and dedicated_head_group:
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            self.head_group = dist.new_group(ranks=ranks)
+            self.head_group = dist.new_group(ranks=ranks, pg_options=_high_priority_options(group))
 
     # ---- encoder gradients ------------------------------------------------------------------
     def allreduce_flat_async(self, flat: torch.Tensor) -> List:
