@@ -247,7 +247,11 @@ static inline int check_conv(const char* who, int N, int H, int W, int Cin, int 
   MLA_REQUIRE(Cin % 64 == 0 || Cin <= 4, "%s: Cin=%d must be a multiple of 64 or <= 4 (stem)", who, Cin);
   MLA_REQUIRE(pad >= 0 && pad < 64 && H < 32768 && W < 32768, "%s: pad/size out of range", who);
   MLA_REQUIRE((long)N * H * W < (1L << 31) / 4, "%s: too many pixels for 32-bit pixel indices", who);
-  MLA_REQUIRE((long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 < 0xFFFFFFF0L, "%s: tensors must be < 4 GiB (32-bit buffer offsets)", who);
+  {   // both tensors of the convolution are addressed with 32-bit byte offsets
+    const long oh = (H + 2 * pad - KH) / stride + 1, ow = (W + 2 * pad - KW) / stride + 1;
+    MLA_REQUIRE((long)N * H * W * Cin * 4 < 0xFFFFFFF0L && (long)N * (oh > 0 ? oh : 0) * (ow > 0 ? ow : 0) * Cout * 4 < 0xFFFFFFF0L,
+                "%s: input and output tensors must each be < 4 GiB (32-bit buffer offsets)", who);
+  }
   return MLA_OK;
 }
 

@@ -275,6 +275,20 @@ def test_conv_f32_every_tile(ops, cfg):
         ops.conv2d_f32_cfg(-1)
 
 
+def test_conv_size_limit_counts_real_tensors(ops):
+    """The 32-bit buffer offsets limit each TENSOR of a convolution to 4 GiB.  The check used to multiply the input pixel count
+    by max(Cin, Cout), which rejected the audio stem at a per-GPU batch of 128 (input 1 channel: 67 MB, output 1.07 GB)."""
+    N, H, W = 130, 1024, 128
+    x = torch.randn((N, H, W, 1), device="cuda")
+    w = torch.randn((7, 7, 1, 64), device="cuda") * 0.1
+    y, _ = ops.conv2d_fwd(x, w, 2, 3)
+    y2, _ = ops.conv2d_fwd(x[-2:].contiguous(), w, 2, 3)
+    assert torch.equal(y[-2:], y2)
+    del y, y2
+    with pytest.raises(MLAHipError):                       # a genuinely too large output is still refused
+        ops.conv2d_fwd(torch.empty((520, H, W, 1), device="cuda"), w, 2, 3, y=torch.empty((1,), device="cuda"))
+
+
 def test_conv_rejects_bad_shapes(ops):
     from mla_hip import MLAHipError
     x = torch.zeros((1, 8, 8, 48), device="cuda")
