@@ -278,6 +278,7 @@ def test_conv_f32_every_tile(ops, cfg):
 def test_conv_size_limit_counts_real_tensors(ops):
     """The 32-bit buffer offsets limit each TENSOR of a convolution to 4 GiB.  The check used to multiply the input pixel count
     by max(Cin, Cout), which rejected the audio stem at a per-GPU batch of 128 (input 1 channel: 67 MB, output 1.07 GB)."""
+    from mla_hip import MLAHipError
     N, H, W = 130, 1024, 128
     x = torch.randn((N, H, W, 1), device="cuda")
     w = torch.randn((7, 7, 1, 64), device="cuda") * 0.1
