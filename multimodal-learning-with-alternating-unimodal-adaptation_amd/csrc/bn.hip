@@ -323,70 +323,87 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dout, co
 // bit for bit.
 // ---------------------------------------------------------------------------------------------------------------------
 
-// idx = kh*3+kw of the FIRST maximum in row-major window order (ATen: `val > maxval || isnan(val)`), as maxpool_fwd_kernel
+// idx = kh*3+kw of the FIRST maximum in row-major window order (ATen: `val > maxval || isnan(val)`), as maxpool_fwd_kernel.
+// A thread forms a 2x2 block of pooled outputs from the 5x5 input pixels they cover (25 loads and BN evaluations instead of
+// 36), walking the input rows top to bottom so that every output still sees its window in row-major order.
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float* __restrict__ out,
                                                                    uint8_t* __restrict__ idx, int N, int H, int W, int C, int OH, int OW) {
-  const int c4n = C >> 2;
-  const size_t total = (size_t)N * OH * OW * c4n;
+  const int c4n = C >> 2, QH = (OH + 1) >> 1, QW = (OW + 1) >> 1;
+  const size_t total = (size_t)N * QH * QW * c4n;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int cg = (int)(i % c4n);
     size_t p = i / c4n;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int n = (int)(p / OH);
+    const int oxq = (int)(p % QW); p /= QW;
+    const int oyq = (int)(p % QH);
+    const int n = (int)(p / QH);
     const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
     const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
-    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int bi[4] = {0, 0, 0, 0};
-    bool first = true;
+    f32x4 best[2][2];
+    int bi[2][2][4];
+    bool first[2][2];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int iy = oy * 2 - 1 + kh;
+    for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+      for (int qx = 0; qx < 2; ++qx) {
+        best[qy][qx] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        first[qy][qx] = true;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bi[qy][qx][e] = 0;
+      }
+    const int iy0 = oyq * 4 - 1, ix0 = oxq * 4 - 1;          // first input row / column of the 5x5 patch
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int iy = iy0 + r;
       if ((unsigned)iy >= (unsigned)H) continue;
+      f32x4 v[5];
+      bool ok[5];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int ix = ox * 2 - 1 + kw;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        f32x4 v = bn_val(reinterpret_cast<const f32x4*>(y)[((size_t)(n * H + iy) * W + ix) * c4n + cg], mu, is, ga, be);
+      for (int c = 0; c < 5; ++c) {
+        const int ix = ix0 + c;
+        ok[c] = (unsigned)ix < (unsigned)W;
+        v[c] = ok[c] ? reinterpret_cast<const f32x4*>(y)[((size_t)(n * H + iy) * W + ix) * c4n + cg] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = v[e] != v[e] ? v[e] : fmaxf(v[e], 0.f);          // relu, NaN kept
-          if (first || v[e] > best[e] || v[e] != v[e]) {
-            best[e] = v[e];
-            bi[e] = kh * 3 + kw;
+      for (int c = 0; c < 5; ++c) {
+        v[c] = bn_val(v[c], mu, is, ga, be);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] = v[c][e] != v[c][e] ? v[c][e] : fmaxf(v[c][e], 0.f);   // relu, NaN kept
+      }
+#pragma unroll
+      for (int qy = 0; qy < 2; ++qy) {
+        const int kh = r - 2 * qy;                            // row of output qy's window
+        if (kh < 0 || kh > 2) continue;
+#pragma unroll
+        for (int qx = 0; qx < 2; ++qx)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int c = 2 * qx + kw;
+            if (!ok[c]) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float ve = v[c][e];
+              if (first[qy][qx] || ve > best[qy][qx][e] || ve != ve) {
+                best[qy][qx][e] = ve;
+                bi[qy][qx][e] = kh * 3 + kw;
+              }
+            }
+            first[qy][qx] = false;
           }
-        }
-        first = false;
       }
     }
-    reinterpret_cast<f32x4*>(out)[i] = best;
-    reinterpret_cast<uchar4*>(idx)[i] = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+#pragma unroll
+    for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+      for (int qx = 0; qx < 2; ++qx) {
+        const int oy = oyq * 2 + qy, ox = oxq * 2 + qx;
+        if (oy >= OH || ox >= OW) continue;
+        const size_t o = ((size_t)(n * OH + oy) * OW + ox) * c4n + cg;
+        reinterpret_cast<f32x4*>(out)[o] = best[qy][qx];
+        reinterpret_cast<uchar4*>(idx)[o] = make_uchar4(bi[qy][qx][0], bi[qy][qx][1], bi[qy][qx][2], bi[qy][qx][3]);
+      }
   }
-}
-
-// upstream gradient of stem pixel (n, iy, ix), channel group cg, before the ReLU mask: gather form of the max-pool scatter
-__device__ __forceinline__ f32x4 pooled_grad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx, int n, int iy, int ix,
-                                              int cg, int c4n, int OH, int OW) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
-  for (int oy = oy0; oy <= oy1; ++oy) {
-    if (oy >= OH) continue;
-    const int kh = iy - (oy * 2 - 1);
-    for (int ox = ox0; ox <= ox1; ++ox) {
-      if (ox >= OW) continue;
-      const int code = kh * 3 + (ix - (ox * 2 - 1));
-      const size_t o = ((size_t)(n * OH + oy) * OW + ox) * c4n + cg;
-      const uchar4 bsel = reinterpret_cast<const uchar4*>(idx)[o];
-      const f32x4 g = reinterpret_cast<const f32x4*>(dpool)[o];
-      if (bsel.x == code) acc[0] += g[0];
-      if (bsel.y == code) acc[1] += g[1];
-      if (bsel.z == code) acc[2] += g[2];
-      if (bsel.w == code) acc[3] += g[3];
-    }
-  }
-  return acc;
 }
 
 // The reduction pass in scatter form: sum_pixels g = sum over POOLED outputs o of dpool[o] * [bn(y[sel(o)]) > 0] (every pooled output
@@ -438,30 +455,69 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_reduce_kernel(const float* 
   }
 }
 
-// The apply pass: dy = gamma * invstd * (g - db/M - xhat * dg/M), g gathered per pixel from the <= 4 windows that may have selected it
+// The apply pass: dy = gamma * invstd * (g - db/M - xhat * dg/M).  A thread owns the 2x2 pixel quad (2a + py, 2b + px): its
+// pixels lie in the four windows (a | a+1, b | b+1) only, at window positions that are compile-time constants --
+//   (0,0): (a,b) code 4;   (0,1): (a,b) 5, (a,b+1) 3;   (1,0): (a,b) 7, (a+1,b) 1;   (1,1): (a,b) 8, (a,b+1) 6, (a+1,b) 2, (a+1,b+1) 0
+// -- so the pooled gradient and the index bytes of each window are loaded once per quad (4 + 4 loads for 4 pixels instead of
+// up to 8 per pixel in the per-pixel gather form).
 __global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
                                                                    const float* __restrict__ y, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, const float* __restrict__ dgamma,
                                                                    const float* __restrict__ dbeta, float* __restrict__ out, int N, int H,
-                                                                   int W, int C, int OH, int OW, int tile_rows) {
-  const int c4n = C >> 2, M = N * H * W;
-  const int cg = threadIdx.x % c4n, rl = threadIdx.x / c4n, nrl = 256 / c4n;
-  const int r0 = blockIdx.x * tile_rows, r1 = min(M, r0 + tile_rows);
-  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
-  const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
-  const float invM = 1.0f / (float)M;
-  const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[cg] * invM, db = reinterpret_cast<const f32x4*>(dbeta)[cg] * invM;
-  for (int r = r0 + rl; r < r1; r += nrl) {
-    const int ix = r % W, t = r / W, iy = t % H, n = t / H;
-    const size_t i = (size_t)r * c4n + cg;
-    const f32x4 xv = reinterpret_cast<const f32x4*>(y)[i];
-    const f32x4 a = bn_val(xv, mu, is, ga, be);
-    f32x4 g = pooled_grad(dpool, idx, n, iy, ix, cg, c4n, OH, OW);
+                                                                   int W, int C, int OH, int OW) {
+  const int c4n = C >> 2, QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+  const size_t total = (size_t)N * QH * QW * c4n;
+  const float invM = 1.0f / ((float)N * (float)H * (float)W);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % c4n);
+    size_t p = i / c4n;
+    const int b = (int)(p % QW); p /= QW;
+    const int a = (int)(p % QH);
+    const int n = (int)(p / QH);
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cg], is = reinterpret_cast<const f32x4*>(invstd)[cg];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[cg], be = reinterpret_cast<const f32x4*>(beta)[cg];
+    const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[cg] * invM, db = reinterpret_cast<const f32x4*>(dbeta)[cg] * invM;
+    f32x4 wg[2][2];                    // pooled gradient of window (a + wy, b + wx); zero outside the pooled grid
+    int ws[2][2][4];                   // its selected positions; -1 outside
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
-    const f32x4 xhat = (xv - mu) * is;
-    reinterpret_cast<f32x4*>(out)[i] = ga * is * (g - db - xhat * dg);
+    for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        const int oy = a + wy, ox = b + wx;
+        if (oy < OH && ox < OW) {
+          const size_t o = ((size_t)(n * OH + oy) * OW + ox) * c4n + cg;
+          wg[wy][wx] = reinterpret_cast<const f32x4*>(dpool)[o];
+          const uchar4 s = reinterpret_cast<const uchar4*>(idx)[o];
+          ws[wy][wx][0] = s.x; ws[wy][wx][1] = s.y; ws[wy][wx][2] = s.z; ws[wy][wx][3] = s.w;
+        } else {
+          wg[wy][wx] = f32x4{0.f, 0.f, 0.f, 0.f};
+          ws[wy][wx][0] = ws[wy][wx][1] = ws[wy][wx][2] = ws[wy][wx][3] = -1;
+        }
+      }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int iy = 2 * a + py, ix = 2 * b + px;
+        if (iy >= H || ix >= W) continue;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wy = 0; wy <= py; ++wy)             // window row a + wy covers pixel row 2a + py at kh = py + 1 - 2 wy
+#pragma unroll
+          for (int wx = 0; wx <= px; ++wx) {
+            const int code = (py + 1 - 2 * wy) * 3 + (px + 1 - 2 * wx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += ws[wy][wx][e] == code ? wg[wy][wx][e] : 0.f;
+          }
+        const size_t o = ((size_t)(n * H + iy) * W + ix) * c4n + cg;
+        const f32x4 xv = reinterpret_cast<const f32x4*>(y)[o];
+        const f32x4 av = bn_val(xv, mu, is, ga, be);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = av[e] > 0.f ? g[e] : 0.f;
+        const f32x4 xhat = (xv - mu) * is;
+        reinterpret_cast<f32x4*>(out)[o] = ga * is * (g - db - xhat * dg);
+      }
   }
 }
 
@@ -577,7 +633,7 @@ extern "C" int mla_bn_relu_maxpool_fwd(const float* y, const float* mean, const 
   if (int rc = bn_check("mla_bn_relu_maxpool_fwd", N * H * W, C)) return rc;
   MLA_REQUIRE(y && mean && invstd && gamma && beta && out && idx && N > 0 && H > 0 && W > 0, "mla_bn_relu_maxpool_fwd: bad argument");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  const size_t n4 = (size_t)N * OH * OW * C / 4;
+  const size_t n4 = (size_t)N * ((OH + 1) / 2) * ((OW + 1) / 2) * (C / 4);     // one thread per 2x2 block of pooled outputs and 4 channels
   bn_relu_maxpool_fwd_kernel<<<ew_grid(n4), 256, 0, (hipStream_t)stream>>>(y, mean, invstd, gamma, beta, out, idx, N, H, W, C, OH, OW);
   MLA_CHECK_LAUNCH("bn_relu_maxpool_fwd_kernel");
   return MLA_OK;
@@ -608,8 +664,8 @@ extern "C" int mla_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const f
     bn_bwd_finalize_kernel<<<cdiv(C, 64), 256, 0, st>>>(scratch, S, C, dgamma, dbeta);
     MLA_CHECK_LAUNCH("bn_bwd_finalize_kernel");
   }
-  const int tr = bn_tile_rows(M);
-  bn_bwd_pooled_apply_kernel<<<cdiv(M, tr), 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, N, H, W, C, OH, OW, tr);
+  const size_t nq = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);     // one thread per 2x2 pixel quad and 4 channels
+  bn_bwd_pooled_apply_kernel<<<ew_grid(nq), 256, 0, st>>>(dpool, idx, y, mean, invstd, gamma, beta, dgamma, dbeta, dy, N, H, W, C, OH, OW);
   MLA_CHECK_LAUNCH("bn_bwd_pooled_apply_kernel");
   return MLA_OK;
 }
