@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-_SPIN_CYCLES = 600_000          # ~0.25 ms per spin kernel
+_SPIN_CYCLES = 300_000          # ~0.13 ms per spin kernel (well above the ~15 us launch noise of the host timer)
 _MAX_STREAMS = 16               # streams created at most while looking for free queues
 _pools: Dict[int, "_Pool"] = {}
 
