@@ -260,6 +260,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
   // prologue / epilogue are exposed with one workgroup per CU (~10 us per tile round on the 1x1 convs).
   int it = 0;
   for (; it + 2 < nIter; ++it) {
+    __builtin_amdgcn_iglp_opt(1);   // the compiler's single-wave small-GEMM interleave of DS / VMEM / MFMA for this block: -1.7 % (same-box A/B;
+                                    // strategy 0, the multi-wave one, +0.8 %)
     const int cur = it & 1;
     load_frags(cur, 0, f0);
     if constexpr (NKK == 2) load_frags(cur, 1, f1);   // both halves' fragments in flight before the first MFMA
