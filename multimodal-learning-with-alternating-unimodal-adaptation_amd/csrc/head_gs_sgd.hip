@@ -7,97 +7,57 @@
 #include "common.h"
 
 #define HEAD_MAXC 128
-#define HEAD_XR 16      // feature slots per lane held in registers by the fast paths (D <= 1024)
 
-// ---- head: one wave per sample -----------------------------------------------------------------
+// ---- head: one workgroup per sample ------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
                                                         const float* __restrict__ bias, const int64_t* __restrict__ labels,
                                                         float* __restrict__ logits, float* __restrict__ rowloss,
                                                         float* __restrict__ dlogits, float* __restrict__ dX, int B, int D,
                                                         int C, float inv_batch) {
-  __shared__ float lg[4][HEAD_MAXC];
+  // One workgroup (4 waves) per sample.  Wave w forms the logits of classes c = w, w+4, ... (each class by ONE wave, lanes
+  // striding the features: the summation order of the one-wave-per-sample form, bit-identical results), wave 0 does the
+  // softmax / loss, then wave w forms dX for the feature slots d = 64 (w + 4 m) + lane.  The one-wave form was a chain of
+  // C dependent reductions and C dependent row reads of W: 206 us at C = 101, D = 768 on the step's critical path.
+  __shared__ float lg[HEAD_MAXC];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
-  if (row >= B) return;  // wave-uniform; no block-level barrier below
+  const int row = blockIdx.x;
   const float* x = X + (size_t)row * D;
-  // One wave per sample is a latency chain (C dependent reductions, then C dependent row reads of W): at C = 101, D = 768 it
-  // ran 467 us on the step's critical path.  For D <= 1024 the sample's features stay in registers and four classes are in
-  // flight at a time (same summation order per class: bit-identical logits); the general loop remains for wider features.
-  const bool fast = D <= 64 * HEAD_XR;
-  float xr[HEAD_XR];
-  if (fast) {
-#pragma unroll
-    for (int k = 0; k < HEAD_XR; ++k) xr[k] = k * 64 + lane < D ? x[k * 64 + lane] : 0.f;
-    for (int c0 = 0; c0 < C; c0 += 4) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < HEAD_XR; ++k) {
-        const int d = k * 64 + lane;
-        if (k * 64 >= D) break;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (c0 + q < C && d < D) acc[q] += xr[k] * W[(size_t)(c0 + q) * D + d];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float sq = wave_sum(acc[q]);
-        if (lane == 0 && c0 + q < C) lg[wave][c0 + q] = sq + bias[c0 + q];
-      }
+  for (int c = wave; c < C; c += 4) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += x[d] * W[(size_t)c * D + d];
+    s = wave_sum(s);
+    if (lane == 0) lg[c] = s + bias[c];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float l0 = lane < C ? lg[lane] : -INFINITY;
+    float l1 = lane + 64 < C ? lg[lane + 64] : -INFINITY;
+    const float m = wave_max(fmaxf(l0, l1));
+    const float e0 = lane < C ? expf(l0 - m) : 0.f, e1 = lane + 64 < C ? expf(l1 - m) : 0.f;
+    const float s = wave_sum(e0 + e1);
+    const long lab_raw = (long)labels[row];
+    const bool lab_ok = lab_raw >= 0 && lab_raw < C;   // out of range: NaN loss (the reference's CE kernel asserts), no OOB LDS read
+    const int lab = lab_ok ? (int)lab_raw : 0;
+    const float lse = m + logf(s);
+    if (lane < C) logits[(size_t)row * C + lane] = l0;
+    if (lane + 64 < C) logits[(size_t)row * C + lane + 64] = l1;
+    if (lane == 0) rowloss[row] = lab_ok ? (lse - lg[lab]) * inv_batch : NAN;
+    __builtin_amdgcn_wave_barrier();
+    const float d0 = (e0 / s - (lane == lab ? 1.f : 0.f)) * inv_batch;
+    const float d1 = (e1 / s - (lane + 64 == lab ? 1.f : 0.f)) * inv_batch;
+    if (lane < C) {
+      lg[lane] = d0;
+      dlogits[(size_t)row * C + lane] = d0;
     }
-  } else {
-    for (int c = 0; c < C; ++c) {
-      float s = 0.f;
-      for (int d = lane; d < D; d += 64) s += x[d] * W[(size_t)c * D + d];
-      s = wave_sum(s);
-      if (lane == 0) lg[wave][c] = s + bias[c];
+    if (lane + 64 < C) {
+      lg[lane + 64] = d1;
+      dlogits[(size_t)row * C + lane + 64] = d1;
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  float l0 = lane < C ? lg[wave][lane] : -INFINITY;
-  float l1 = lane + 64 < C ? lg[wave][lane + 64] : -INFINITY;
-  const float m = wave_max(fmaxf(l0, l1));
-  const float e0 = lane < C ? expf(l0 - m) : 0.f, e1 = lane + 64 < C ? expf(l1 - m) : 0.f;
-  const float s = wave_sum(e0 + e1);
-  const long lab_raw = (long)labels[row];
-  const bool lab_ok = lab_raw >= 0 && lab_raw < C;   // out of range: NaN loss (the reference's CE kernel asserts), no OOB LDS read
-  const int lab = lab_ok ? (int)lab_raw : 0;
-  const float lse = m + logf(s);
-  if (lane < C) logits[(size_t)row * C + lane] = l0;
-  if (lane + 64 < C) logits[(size_t)row * C + lane + 64] = l1;
-  if (lane == 0) rowloss[row] = lab_ok ? (lse - lg[wave][lab]) * inv_batch : NAN;
-  __builtin_amdgcn_wave_barrier();
-  const float d0 = (e0 / s - (lane == lab ? 1.f : 0.f)) * inv_batch;
-  const float d1 = (e1 / s - (lane + 64 == lab ? 1.f : 0.f)) * inv_batch;
-  if (lane < C) {
-    lg[wave][lane] = d0;
-    dlogits[(size_t)row * C + lane] = d0;
-  }
-  if (lane + 64 < C) {
-    lg[wave][lane + 64] = d1;
-    dlogits[(size_t)row * C + lane + 64] = d1;
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (fast) {          // dX: all feature slots of the lane accumulate side by side, the row reads of W pipeline across classes
-    float a[HEAD_XR];
-#pragma unroll
-    for (int k = 0; k < HEAD_XR; ++k) a[k] = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float dl = lg[wave][c];
-#pragma unroll
-      for (int k = 0; k < HEAD_XR; ++k) {
-        if (k * 64 >= D) break;
-        const int d = k * 64 + lane;
-        if (d < D) a[k] += dl * W[(size_t)c * D + d];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < HEAD_XR; ++k)
-      if (k * 64 + lane < D) dX[(size_t)row * D + k * 64 + lane] = a[k];
-    return;
-  }
-  for (int d = lane; d < D; d += 64) {
+  __syncthreads();
+  for (int d = wave * 64 + lane; d < D; d += 256) {
     float a = 0.f;
-    for (int c = 0; c < C; ++c) a += lg[wave][c] * W[(size_t)c * D + d];
+    for (int c = 0; c < C; ++c) a += lg[c] * W[(size_t)c * D + d];
     dX[(size_t)row * D + d] = a;
   }
 }
@@ -136,7 +96,7 @@ extern "C" int mla_head_ce_fwd_bwd(const float* X, const float* W, const float* 
   hipStream_t st = (hipStream_t)stream;
   float* dlogits = ws;
   float* rowloss = ws + (size_t)B * C;
-  head_fwd_kernel<<<cdiv(B, 4), 256, 0, st>>>(X, W, b, labels, logits, rowloss, dlogits, dX, B, D, C, inv_batch);
+  head_fwd_kernel<<<B, 256, 0, st>>>(X, W, b, labels, logits, rowloss, dlogits, dX, B, D, C, inv_batch);
   MLA_CHECK_LAUNCH("head_fwd_kernel");
   head_grad_kernel<<<dim3(cdiv(D, 256), C), 256, 0, st>>>(X, dlogits, rowloss, dW, db, loss, B, D, C);
   MLA_CHECK_LAUNCH("head_grad_kernel");
@@ -278,42 +238,19 @@ __global__ __launch_bounds__(256) void gs_update_kernel(float* __restrict__ Pl, 
   if (lane == 0) rowsq[i] = q;
 }
 // C: Pl /= ||Pl||_F ; Gout[c][i] = sum_j G[c][j] Pl[i][j]
+// One workgroup (4 waves) per row of Pl: every wave forms the norm (same order: bit-identical), wave w normalises the columns
+// j = 64 (w + 4 m) + lane and, after a barrier, projects the classes c = w, w+4, ... (each class by one wave in the lane / stride
+// order of the one-wave-per-row form).  At C = 101 that form was a chain of 101 dependent reductions per row: 300 us.
 __global__ __launch_bounds__(256) void gs_finish_kernel(float* __restrict__ Pl, const float* __restrict__ rowsq,
                                                          const float* __restrict__ G, float* __restrict__ Gout, int D, int C) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= D) return;
+  const int i = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double t = 0.0;
   for (int j = lane; j < D; j += 64) t += (double)rowsq[j];
   t = wave_sum_d(t);
   const float nrm = (float)sqrt(t);
-  if (D <= 64 * HEAD_XR) {     // the normalised row stays in registers, four classes reduce side by side (same order per class:
-    float pr[HEAD_XR];         // bit-identical); the one-class-at-a-time loop below took 427 us at C = 101, D = 768
-#pragma unroll
-    for (int k = 0; k < HEAD_XR; ++k) {
-      const int j = k * 64 + lane;
-      pr[k] = j < D ? Pl[(size_t)i * D + j] / nrm : 0.f;
-      if (j < D) Pl[(size_t)i * D + j] = pr[k];
-    }
-    for (int c0 = 0; c0 < C; c0 += 4) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < HEAD_XR; ++k) {
-        if (k * 64 >= D) break;
-        const int j = k * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (c0 + q < C && j < D) acc[q] += G[(size_t)(c0 + q) * D + j] * pr[k];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float sq = wave_sum(acc[q]);
-        if (lane == 0 && c0 + q < C) Gout[(size_t)(c0 + q) * D + i] = sq;
-      }
-    }
-    return;
-  }
-  for (int j = lane; j < D; j += 64) Pl[(size_t)i * D + j] = Pl[(size_t)i * D + j] / nrm;
-  for (int c = 0; c < C; ++c) {
+  for (int j = wave * 64 + lane; j < D; j += 256) Pl[(size_t)i * D + j] = Pl[(size_t)i * D + j] / nrm;
+  __syncthreads();                       // the row is complete (and visible to the workgroup) before it is read back
+  for (int c = wave; c < C; c += 4) {
     float s = 0.f;
     for (int j = lane; j < D; j += 64) s += G[(size_t)c * D + j] * Pl[(size_t)i * D + j];
     s = wave_sum(s);
@@ -331,7 +268,7 @@ extern "C" int mla_gs_project(float* Pl, const float* r, float* G, int D, int C,
   MLA_CHECK_LAUNCH("gs_k_kernel");
   gs_update_kernel<<<cdiv(D, 4), 256, 0, st>>>(Pl, r, k, rowsq, D, alpha);
   MLA_CHECK_LAUNCH("gs_update_kernel");
-  gs_finish_kernel<<<cdiv(D, 4), 256, 0, st>>>(Pl, rowsq, G, Gtmp, D, C);
+  gs_finish_kernel<<<D, 256, 0, st>>>(Pl, rowsq, G, Gtmp, D, C);
   MLA_CHECK_LAUNCH("gs_finish_kernel");
   if (hipMemcpyAsync(G, Gtmp, (size_t)C * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
     mla_set_error("mla_gs_project: hipMemcpyAsync failed");
