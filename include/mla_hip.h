@@ -235,6 +235,10 @@ int mla_linear_dgrad_split(const float* dy, const void* wsplit, float* dx, const
 size_t mla_linear_wgrad_split_ws_bytes(int M, int K, int N);
 int mla_linear_wgrad_split(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows, int x_off,
                            int K, int N, void* ws, size_t ws_bytes, void* stream);
+/* ... and the bias gradient dbias[N] = column sums of dy out of the same pass (dbias may be NULL); workspace as reported by
+ * mla_linear_wgrad_split_ws_bytes (weight slabs + one bias row per split-K range). */
+int mla_linear_wgrad_split_bias(const float* x, const float* dy, float* dw_kn, float* dbias, int groups, int rows,
+                                int x_group_rows, int x_off, int K, int N, void* ws, size_t ws_bytes, void* stream);
 /* out[c] = sum_rows x[r][c]  (bias gradients).  ws: mla_colreduce_ws_elems(M, C) floats; C % 64 == 0. */
 size_t mla_colreduce_ws_elems(int M, int C);
 int mla_colsum_rows(const float* x, float* out, float* ws, int M, int C, void* stream);

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
 #define WGS_CHUNK 2048
 template <int BI, int BJ, int WI, int WJ>
 __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                                        float* __restrict__ part, const IGemmGeom g, int span) {
+                                                                        float* __restrict__ part, const IGemmGeom g, int span,
+                                                                        float* __restrict__ bias_part = nullptr) {
   static_assert(WI * WJ == 4 || WI * WJ == 8, "4 or 8 waves");
   constexpr int NT = 64 * WI * WJ;
   constexpr int MI = BI / WI / 32, NI = BJ / WJ / 32;
@@ -375,6 +376,8 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_split_kernel(const floa
   };
   Frags f0, f1;
 
+  const bool do_bias = bias_part != nullptr && ti == 0 && t == 0;   // one workgroup per (column tile, pixel range)
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
   for (int c_begin = m_begin; c_begin < m_end; c_begin += WGS_CHUNK) {
     const int c_end = min(m_end, c_begin + WGS_CHUNK);
     __syncthreads();  // previous sub-chunk's readers are done with rowoff / As / Bs
@@ -429,6 +432,10 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_split_kernel(const floa
     auto store_tiles = [&](int buf) {
       store_op(As + buf * ASZ + x_st, BI, xreg, std::integral_constant<int, XPX>{});
       store_op(Bs + buf * BSZ + y_st, BJ, yreg, std::integral_constant<int, YPX>{});
+      if (do_bias) {            // Linear bias gradient = column sums of dY: the tile is in registers here anyway
+#pragma unroll
+        for (int q = 0; q < YPX; ++q) bacc += yreg[q];
+      }
     };
 
     const int nIter = (c_end - c_begin + BK - 1) / BK;
@@ -466,6 +473,18 @@ __global__ __launch_bounds__(64 * WI * WJ, 1) void wgrad_split_kernel(const floa
     }
   }
 
+  if (do_bias) {     // reduce the per-thread sums over the YG pixel groups (fixed order), write this range's partial bias row
+    __syncthreads();                                  // the last stage's fragment reads of As are done
+    float* red = reinterpret_cast<float*>(As);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[yg * BJ + yc * 4 + e] = bacc[e];
+    __syncthreads();
+    if (tid < BJ) {
+      float sb = 0.f;
+      for (int k2 = 0; k2 < YG; ++k2) sb += red[k2 * BJ + tid];
+      bias_part[(size_t)by * gCO + tj * BJ + tid] = sb;
+    }
+  }
   float* slab = part + ((size_t)by * g.T + t) * gC * gCO;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -748,11 +767,18 @@ extern "C" int mla_linear_dgrad_split(const float* dy, const void* wsplit, float
 extern "C" size_t mla_linear_wgrad_split_ws_bytes(int M, int K, int N) {
   int span, splits;
   wgrad_split_plan(M, K, N, 1, &span, &splits);
-  return (size_t)splits * K * N * sizeof(float);
+  return (size_t)splits * K * N * sizeof(float) + (size_t)splits * N * sizeof(float);     // weight slabs + bias rows
 }
 
 extern "C" int mla_linear_wgrad_split(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows,
                                       int x_off, int K, int N, void* ws, size_t ws_bytes, void* stream) {
+  return mla_linear_wgrad_split_bias(x, dy, dw_kn, nullptr, groups, rows, x_group_rows, x_off, K, N, ws, ws_bytes, stream);
+}
+
+// ... and, with dbias != null, the bias gradient dbias[N] = column sums of dy out of the same pass (the dy tiles are staged
+// for the MFMA anyway; replaces a separate column-reduction kernel pair per Linear layer)
+extern "C" int mla_linear_wgrad_split_bias(const float* x, const float* dy, float* dw_kn, float* dbias, int groups, int rows,
+                                           int x_group_rows, int x_off, int K, int N, void* ws, size_t ws_bytes, void* stream) {
   MLA_REQUIRE(x && dy && dw_kn && ws, "mla_linear_wgrad_split: null pointer");
   IGemmGeom g;
   if (int rc = linear_geom("mla_linear_wgrad_split", g, groups, rows, x_group_rows, x_off, rows, 0, K, N)) return rc;
@@ -760,17 +786,19 @@ extern "C" int mla_linear_wgrad_split(const float* x, const float* dy, float* dw
   hipStream_t st = (hipStream_t)stream;
   int span, splits;
   wgrad_split_plan(g.M, K, N, 1, &span, &splits);
-  const size_t need = (size_t)splits * K * N * sizeof(float);
+  const size_t need = (size_t)splits * K * N * sizeof(float) + (dbias ? (size_t)splits * N * sizeof(float) : 0);
   if (ws_bytes < need) {
     mla_set_error("mla_linear_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
     return MLA_ERR_WORKSPACE;
   }
   float* part = (float*)ws;
+  float* bias_part = dbias ? part + (size_t)splits * K * N : nullptr;
   if (K % 128 == 0 && N % 128 == 0) {
-    wgrad_split_kernel<128, 128, 2, 4><<<dim3((K / 128) * (N / 128), splits), 512, 0, st>>>(x, dy, part, g, span);
+    wgrad_split_kernel<128, 128, 2, 4><<<dim3((K / 128) * (N / 128), splits), 512, 0, st>>>(x, dy, part, g, span, bias_part);
   } else {
-    wgrad_split_kernel<64, 64, 2, 2><<<dim3((K / 64) * (N / 64), splits), 256, 0, st>>>(x, dy, part, g, span);
+    wgrad_split_kernel<64, 64, 2, 2><<<dim3((K / 64) * (N / 64), splits), 256, 0, st>>>(x, dy, part, g, span, bias_part);
   }
   MLA_CHECK_LAUNCH("wgrad_split_kernel");
-  return mla_wgrad_reduce(part, dw_kn, (size_t)K * N / 4, splits, st);
+  if (int rc = mla_wgrad_reduce(part, dw_kn, (size_t)K * N / 4, splits, st)) return rc;
+  return dbias ? mla_wgrad_reduce(bias_part, dbias, (size_t)N / 4, splits, st) : MLA_OK;
 }

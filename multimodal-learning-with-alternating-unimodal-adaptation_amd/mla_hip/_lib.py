@@ -83,6 +83,7 @@ PROTOTYPES = {
     "mla_linear_dgrad_split": (_I, [_P] * 5 + [_I] * 8 + [_P]),
     "mla_linear_wgrad_split_ws_bytes": (_Z, [_I, _I, _I]),
     "mla_linear_wgrad_split": (_I, [_P, _P, _P] + [_I] * 6 + [_P, _Z, _P]),
+    "mla_linear_wgrad_split_bias": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "mla_colreduce_ws_elems": (_Z, [_I, _I]),
     "mla_colsum_rows": (_I, [_P, _P, _P, _I, _I, _P]),
     "mla_layernorm_fwd": (_I, [_P] * 6 + [_I, _I, _F, _P]),

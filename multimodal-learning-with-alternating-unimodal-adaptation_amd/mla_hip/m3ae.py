@@ -49,6 +49,9 @@ def sincos_pos_embed(embed_dim: int, length: int, two_d: bool) -> torch.Tensor:
     return torch.from_numpy(emb.astype(np.float32))
 
 
+# measurement switch (same-box A/B): 0 = bias gradients by separate column-reduction launches
+FUSE_BIAS_GRAD = os.environ.get("MLA_FUSE_BIAS_GRAD", "1") != "0"
+
 class M3AEEncoder(FlatModule):
     """nn.Module face (module.py): parameters under the reference's names, order and layouts -- nn.Linear weights
     (out, in) as transposed views of the [in][out] GEMM operands, type embeddings / cls as (1,1,D) -- registered as
@@ -397,6 +400,15 @@ class M3AEEncoder(FlatModule):
         return feat
 
     # ------------------------------------------------------------------------------------------
+    def _wgrad_bias(self, x, dy, dw, db, wgw, red, M: int, K: int, N: int, st) -> None:
+        """Weight and bias gradient of one Linear (dw = x^T dy, db = column sums of dy).  On the split arithmetic the bias
+        gradient comes out of the weight-gradient kernel's own pass over dy (no separate column-reduction launches)."""
+        if self.split and FUSE_BIAS_GRAD:
+            ops.linear_wgrad(x, dy, dw, wgw, 1, M, K, N, stream=st, split=True, dbias=db)
+        else:
+            ops.colsum_rows(dy, db, red, M, N, stream=st)
+            ops.linear_wgrad(x, dy, dw, wgw, 1, M, K, N, stream=st, split=self.split)
+
     def backward_from_pooled(self, dfeat: torch.Tensor, P: Optional[int] = None) -> None:
         ws = self._ws
         self._bwd_ws(ws)
@@ -415,17 +427,14 @@ class M3AEEncoder(FlatModule):
             P_ = lambda nm: self.p[f"encoder.blocks.{i}.{nm}"]
             G_ = lambda nm: self.g[f"encoder.blocks.{i}.{nm}"]
             # ---- MLP: xout = xmid + fc2(gelu(fc1(LN2(xmid))))
-            ops.colsum_rows(dx, G_("transformer_mlp.fc2.bias"), red, M, D, stream=st)
-            ops.linear_wgrad(bk["gl"], dx, G_("transformer_mlp.fc2.weight"), wgw, 1, M, 4 * D, D, stream=st, split=self.split)
+            self._wgrad_bias(bk["gl"], dx, G_("transformer_mlp.fc2.weight"), G_("transformer_mlp.fc2.bias"), wgw, red, M, 4 * D, D, st)
             ops.linear_dgrad(dx, P_("transformer_mlp.fc2.weight"), ws["du"], wtw, 1, M, 4 * D, D, gelu_src=bk["u"], stream=st, wsplit=self._w(f"encoder.blocks.{i}.transformer_mlp.fc2.weight", 1))
-            ops.colsum_rows(ws["du"], G_("transformer_mlp.fc1.bias"), red, M, 4 * D, stream=st)
-            ops.linear_wgrad(bk["h2"], ws["du"], G_("transformer_mlp.fc1.weight"), wgw, 1, M, D, 4 * D, stream=st, split=self.split)
+            self._wgrad_bias(bk["h2"], ws["du"], G_("transformer_mlp.fc1.weight"), G_("transformer_mlp.fc1.bias"), wgw, red, M, D, 4 * D, st)
             ops.linear_dgrad(ws["du"], P_("transformer_mlp.fc1.weight"), dB_, wtw, 1, M, D, 4 * D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.transformer_mlp.fc1.weight", 1))   # d h2
             ops.layernorm_bwd(dB_, bk["xmid"], P_("layer_norm2.weight"), bk["st"][2], bk["st"][3], dB_, G_("layer_norm2.weight"),
                               G_("layer_norm2.bias"), red, M, D, add=dx, stream=st)                             # d xmid -> dB_
             # ---- attention: xmid = x + fc(PV)
-            ops.colsum_rows(dB_, G_("attention.fc.bias"), red, M, D, stream=st)
-            ops.linear_wgrad(bk["o"], dB_, G_("attention.fc.weight"), wgw, 1, M, D, D, stream=st, split=self.split)
+            self._wgrad_bias(bk["o"], dB_, G_("attention.fc.weight"), G_("attention.fc.bias"), wgw, red, M, D, D, st)
             ops.linear_dgrad(dB_, P_("attention.fc.weight"), dC, wtw, 1, M, D, D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.fc.weight", 1))                    # d o (B,n,D)
             if self.attention == "fused":
                 ops.attention_bwd(dC, bk["qkv"], bk["o"], bk["lse"], ws["pm"], ws["dqkv"], ws["dvec"], B, H, n, hd, stream=st)
@@ -437,8 +446,7 @@ class M3AEEncoder(FlatModule):
                 ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, ss, (n * 3 * D, hd, 3 * D, 1), qs, scale, b_off=D, stream=st)     # dQ = s dS K
                 ops.bgemm(ws["dP"], bk["qkv"], ws["dqkv"], B, H, n, hd, n, (H * n * n, n * n, 1, n), (n * 3 * D, hd, 3 * D, 1), qs, scale,
                           c_off=D, stream=st)                                                                                                # dK = s dS^T Q
-            ops.colsum_rows(ws["dqkv"], G_("attention.qkv_linear.bias"), red, M, 3 * D, stream=st)
-            ops.linear_wgrad(bk["h1"], ws["dqkv"], G_("attention.qkv_linear.weight"), wgw, 1, M, D, 3 * D, stream=st, split=self.split)
+            self._wgrad_bias(bk["h1"], ws["dqkv"], G_("attention.qkv_linear.weight"), G_("attention.qkv_linear.bias"), wgw, red, M, D, 3 * D, st)
             ops.linear_dgrad(ws["dqkv"], P_("attention.qkv_linear.weight"), dC, wtw, 1, M, D, 3 * D, stream=st, wsplit=self._w(f"encoder.blocks.{i}.attention.qkv_linear.weight", 1))  # d h1
             ops.layernorm_bwd(dC, bk["x"], P_("layer_norm1.weight"), bk["st"][0], bk["st"][1], dC, G_("layer_norm1.weight"),
                               G_("layer_norm1.bias"), red, M, D, add=dB_, stream=st)                            # d x -> dC

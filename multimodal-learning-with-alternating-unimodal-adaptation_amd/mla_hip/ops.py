@@ -477,12 +477,15 @@ def linear_wgrad_ws_bytes(M: int, K: int, N: int, split: bool = False) -> int:
 
 
 def linear_wgrad(x, dy, dw_kn, ws, groups: int, rows: int, K: int, N: int, x_group_rows: Optional[int] = None, x_off: int = 0,
-                 stream: Optional[int] = None, split: bool = False):
+                 stream: Optional[int] = None, split: bool = False, dbias: Optional[torch.Tensor] = None):
+    """dw_kn = x^T dy (K, N).  split + dbias: the bias gradient (column sums of dy) comes out of the same pass."""
     if split:
-        check(_lib.load().mla_linear_wgrad_split(_p(x), _p(dy), _p(dw_kn), groups, rows, x_group_rows or rows, x_off, K, N,
-                                                 _p(ws), ws.numel() * ws.element_size(), stream or cur_stream()),
-              "mla_linear_wgrad_split")
+        check(_lib.load().mla_linear_wgrad_split_bias(_p(x), _p(dy), _p(dw_kn), _p(dbias), groups, rows, x_group_rows or rows, x_off,
+                                                      K, N, _p(ws), ws.numel() * ws.element_size(), stream or cur_stream()),
+              "mla_linear_wgrad_split_bias")
         return
+    if dbias is not None:
+        raise MLAHipError("linear_wgrad: the fused bias gradient exists on the split arithmetic only (use colsum_rows)")
     check(_lib.load().mla_linear_wgrad(_p(x), _p(dy), _p(dw_kn), groups, rows, x_group_rows or rows, x_off, K, N, _p(ws),
                                        ws.numel() * ws.element_size(), stream or cur_stream()), "mla_linear_wgrad")
 

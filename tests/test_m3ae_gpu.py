@@ -8,6 +8,8 @@ element-wise denominator (Q2) is ill-conditioned on mixed-sign transformer featu
 import os
 
 import numpy as np
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -70,6 +72,15 @@ def test_linear_fwd_dgrad_wgrad(ops, groups, rows, xg, xo, yg, yo, K, N):
     db = torch.empty(N, device="cuda")
     ops.colsum_rows(dy.cuda(), db, torch.empty(ops.colreduce_ws_elems(M, N), device="cuda"), M, N)
     assert_close(db, dy.sum(0), atol=1e-5, rtol=1e-5, name="bias grad (colsum_rows)")
+    # split arithmetic: weight gradient with the bias gradient out of the same pass over dy
+    ws2 = torch.empty(ops.linear_wgrad_ws_bytes(M, K, N, True) // 4 + 4, device="cuda")
+    dw2, db2 = torch.empty((K, N), device="cuda"), torch.full((N,), float("nan"), device="cuda")
+    ops.linear_wgrad(x.cuda(), dy.cuda(), dw2, ws2, groups, rows, K, N, x_group_rows=xg, x_off=xo, split=True, dbias=db2)
+    assert_close(dw2, xs.reshape(M, K).t() @ dy, atol=0, rtol=2e-5, name="linear wgrad (split, fused bias)")
+    assert_close(db2, dy.double().sum(0), atol=2e-6 * math.sqrt(M), rtol=2e-5, name="bias grad (fused into the split weight gradient)")
+    dw3 = torch.empty((K, N), device="cuda")
+    ops.linear_wgrad(x.cuda(), dy.cuda(), dw3, ws2, groups, rows, K, N, x_group_rows=xg, x_off=xo, split=True)
+    assert torch.equal(dw3, dw2), "the fused bias sums must not change the weight gradient"
 
 
 @pytest.mark.parametrize("M,D", [(771, 768), (5, 768), (1000, 512), (130, 1024)])
