@@ -49,34 +49,60 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dx += add (residual-branch gradient)
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w;  dx += add (residual-branch gradient).
+// A workgroup owns LN_TR = 16 rows (4 per wave) and also forms the column sums of the affine gradients over them --
+// sum dy (bias) and sum dy * xhat (weight) -- from the values it holds anyway: partial[tile][2][D], finalized by
+// colreduce_finalize_kernel.  (A separate column-reduction pass re-read dy and x: 19 us per LayerNorm at 16448 x 768.)
+#define LN_TR 16
 template <int PER>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ w, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* add, float* dx,
-                                                         int M, int D) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float mu = mean[row], rs = rstd[row];
-  float g[PER], xh[PER];
-  float s1 = 0.f, s2 = 0.f;
+                                                         float* __restrict__ partial, int M, int D) {
+  __shared__ float red[2][4][PER * 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float cb[PER], cw[PER], wv[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const int c = k * 64 + lane;
-    const size_t i = (size_t)row * D + c;
-    g[k] = dy[i] * w[c];
-    xh[k] = (x[i] - mu) * rs;
-    s1 += g[k];
-    s2 += g[k] * xh[k];
+    cb[k] = cw[k] = 0.f;
+    wv[k] = w[k * 64 + lane];
   }
-  s1 = wave_sum(s1) / D;
-  s2 = wave_sum(s2) / D;
+  for (int rr = 0; rr < LN_TR / 4; ++rr) {
+    const int row = blockIdx.x * LN_TR + rr * 4 + wave;       // wave-uniform
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    float g[PER], xh[PER];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const size_t i = (size_t)row * D + k * 64 + lane;
+      const float dv = dy[i];
+      g[k] = dv * wv[k];
+      xh[k] = (x[i] - mu) * rs;
+      s1 += g[k];
+      s2 += g[k] * xh[k];
+      cb[k] += dv;
+      cw[k] += dv * xh[k];
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const size_t i = (size_t)row * D + k * 64 + lane;
+      float r = rs * (g[k] - s1 - xh[k] * s2);
+      if (add) r += add[i];
+      dx[i] = r;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const size_t i = (size_t)row * D + k * 64 + lane;
-    float r = rs * (g[k] - s1 - xh[k] * s2);
-    if (add) r += add[i];
-    dx[i] = r;
+    red[0][wave][k * 64 + lane] = cb[k];
+    red[1][wave][k * 64 + lane] = cw[k];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    partial[((size_t)blockIdx.x * 2 + 0) * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    partial[((size_t)blockIdx.x * 2 + 1) * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
   }
 }
 
@@ -136,7 +162,10 @@ static int colreduce_tile_rows(int M) {
   if (t < 64) t = 64;
   return (int)t;
 }
-extern "C" size_t mla_colreduce_ws_elems(int M, int C) { return (size_t)cdiv(M, colreduce_tile_rows(M)) * 2 * C; }
+extern "C" size_t mla_colreduce_ws_elems(int M, int C) {   // column sums: row tiles of colreduce_tile_rows; LayerNorm backward: tiles of 16 rows
+  const size_t a = (size_t)cdiv(M, colreduce_tile_rows(M)) * 2 * C, b = (size_t)cdiv(M, 16) * 2 * C;
+  return a > b ? a : b;
+}
 
 extern "C" int mla_colsum_rows(const float* x, float* out, float* ws, int M, int C, void* stream) {
   MLA_REQUIRE(x && out && ws && M > 0 && C > 0 && C % 64 == 0, "mla_colsum_rows: bad argument (C %% 64 == 0)");
@@ -166,16 +195,14 @@ extern "C" int mla_layernorm_bwd(const float* dy, const float* x, const float* w
   MLA_REQUIRE(dy && x && w && mean && rstd && dx && dw && db && ws && M > 0, "mla_layernorm_bwd: bad argument");
   MLA_REQUIRE(D == 512 || D == 768 || D == 1024, "mla_layernorm_bwd: D=%d unsupported (512, 768, 1024)", D);
   hipStream_t st = (hipStream_t)stream;
-  const int tr = colreduce_tile_rows(M), nt = cdiv(M, tr);
-  colreduce_kernel<1><<<dim3(D / 64, nt), 256, 0, st>>>(dy, x, mean, rstd, ws, M, D, tr);
-  MLA_CHECK_LAUNCH("colreduce_kernel<1>");
+  const int nt = cdiv(M, LN_TR);
+  // dx may alias dy or add (each row is fully read into registers before it is written)
+  if (D == 512) ln_bwd_dx_kernel<8><<<nt, 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, ws, M, D);
+  else if (D == 768) ln_bwd_dx_kernel<12><<<nt, 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, ws, M, D);
+  else ln_bwd_dx_kernel<16><<<nt, 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, ws, M, D);
+  MLA_CHECK_LAUNCH("ln_bwd_dx_kernel");
   colreduce_finalize_kernel<<<cdiv(D, 4), 256, 0, st>>>(ws, nt, D, db, dw);
   MLA_CHECK_LAUNCH("colreduce_finalize_kernel");
-  // dx may alias dy or add (each row is fully read into registers before it is written)
-  if (D == 512) ln_bwd_dx_kernel<8><<<cdiv(M, 4), 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, M, D);
-  else if (D == 768) ln_bwd_dx_kernel<12><<<cdiv(M, 4), 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, M, D);
-  else ln_bwd_dx_kernel<16><<<cdiv(M, 4), 256, 0, st>>>(dy, x, w, mean, rstd, add, dx, M, D);
-  MLA_CHECK_LAUNCH("ln_bwd_dx_kernel");
   return MLA_OK;
 }
 
