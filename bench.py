@@ -177,8 +177,41 @@ def main() -> None:
     sync()
     dt_serial = time.perf_counter() - t1
     ops.TIMER = None
+    # SURVEY 8d's un-fused BatchNorm accounting needs the time of the reduction passes that normally run inside the input-gradient
+    # epilogues: measured here, in this run, by a second serialized event-instrumented pass with those fusions switched off
+    # (every BatchNorm backward then runs its own reduce kernel; encoder.FUSE_BN_REDUCE is read at call time).
+    from mla_hip import encoder as _enc
+    timer_unfused = ops.KernelTimer()
+    if world == 1:
+        _enc.FUSE_BN_REDUCE = False
+        trainer.train_step(spec, image, label, 0, len_dl)
+        sync()
+        ops.TIMER = timer_unfused
+        for s in range(a.steps):
+            trainer.train_step(spec, image, label, (a.warmup + s) % len_dl, len_dl)
+        sync()
+        ops.TIMER = None
+        _enc.FUSE_BN_REDUCE = True
     trainer.set_overlap(overlapped)
     per_rank_ms = [round(dt / a.steps * 1e3, 3)]
+    dist_diag = None
+    if world > 1:
+        # self-diagnosing multi-GPU record: a few more pipelined steps with HIP events around the packed head exchange (critical
+        # path) and around the wait for each encoder's gradient all-reduce in front of its SGD, per rank
+        trainer.dist_events = {}
+        for s in range(min(a.steps, 10)):
+            trainer.train_step(spec, image, label, (a.warmup + s) % len_dl, len_dl)
+        sync()
+        ev = trainer.dist_event_ms()
+        trainer.dist_events = None
+        mine2 = torch.tensor([ev.get("head_exchange", (0, 0.0))[1], ev.get("grad_wait", (0, 0.0))[1]], device=dev, dtype=torch.float64)
+        all2 = [torch.zeros_like(mine2) for _ in range(world)]
+        dist.all_gather(all2, mine2)
+        dist_diag = {"head_exchange_ms_per_phase_per_rank": [round(float(x[0]), 4) for x in all2],
+                     "encoder_grad_wait_ms_before_sgd_per_rank": [round(float(x[1]), 4) for x in all2],
+                     "note": "HIP events on the stream each wait is enqueued on, pipelined steps after the timed region; the head exchange "
+                             "(14 KB, own high-priority communicator) is on the step's critical path twice per step, the gradient wait "
+                             "(44.7 MB per encoder in 16 MB buckets, issued right after that encoder's backward) only delays that encoder's SGD"}
     if world > 1:
         # MAX over ranks is the reported time; the per-rank values and the serialized (no stream pipeline) pass travel along so
         # that a first real multi-GPU run shows by itself whether a rank lags or the exchange serialises behind the backward
@@ -211,7 +244,7 @@ def main() -> None:
         del t2, m2
     if rank == 0:
         summ = timer.summary()
-        ig = {"ms": 0.0, "work": 0.0, "launches": 0}
+        ig = {"ms": 0.0, "ms_raw": 0.0, "work": 0.0, "launches": 0}
         for k in ("conv_fwd", "conv_dgrad"):                    # both are igemm_kernel launches
             for f in ig:
                 ig[f] += summ.get(k, {}).get(f, 0)
@@ -252,18 +285,20 @@ def main() -> None:
                         "moved_GBps": round(hbm["moved"] / (hbm["ms"] * 1e-3) / 1e9, 1),
                         "algorithmic_GB_per_step": round(hbm["work"] / a.steps / 1e9, 2), "ms_per_step": round(hbm["ms"] / a.steps, 3)}
             # SURVEY 8d's accounting of the same BatchNorm layers for the UN-fused algorithm (12 B/elem forward + 20 B/elem backward
-            # over every conv output element): what the family would have to move without the fusions, over the time it takes now.
-            # Not the `frac` above: about 0.85 ms per step of reduction work runs inside the gather-GEMM epilogues (same-box A/B of
-            # MLA_FUSE_BN_REDUCE: 36 reduce launches = 1.25 ms removed, serialized step -0.40 ms) and is added back here.
-            elems = 0
-            for enc in (model.audio_net, model.visual_net):
-                ws_e = enc._ws
-                elems += ws_e["y_stem"].numel() + sum(blk[k].numel() for blk in ws_e["blocks"] for k in ("y1", "y2", "yd") if k in blk)
-            survey_gb = 32.0 * elems / 1e9
-            t_incl = hbm["ms"] / a.steps + 0.85
-            hbm_roof["survey_8d_accounting"] = {"GB_per_step": round(survey_gb, 2), "ms_per_step_incl_epilogue_reductions": round(t_incl, 3),
-                                                "GBps": round(survey_gb / (t_incl * 1e-3), 1),
-                                                "frac": round(survey_gb / (t_incl * 1e-3) / PEAK_HBM_GBPS, 4)}
+            # over every conv output element) over the BatchNorm-family time MEASURED in this run with the epilogue reductions
+            # switched off (second serialized pass above: every backward runs its own reduce kernel).  Not the `frac` above.
+            su = timer_unfused.summary()
+            t_unf = sum(su.get(k, {}).get("ms", 0.0) for k in ("bn_fwd", "bn_bwd")) / a.steps
+            if t_unf > 0:
+                elems = 0
+                for enc in (model.audio_net, model.visual_net):
+                    ws_e = enc._ws
+                    elems += ws_e["y_stem"].numel() + sum(blk[k].numel() for blk in ws_e["blocks"] for k in ("y1", "y2", "yd") if k in blk)
+                survey_gb = 32.0 * elems / 1e9
+                hbm_roof["survey_8d_accounting"] = {"GB_per_step": round(survey_gb, 2), "ms_per_step_unfused_reductions_measured": round(t_unf, 3),
+                                                    "GBps": round(survey_gb / (t_unf * 1e-3), 1),
+                                                    "frac": round(survey_gb / (t_unf * 1e-3) / PEAK_HBM_GBPS, 4),
+                                                    "stalled_brackets_replaced_by_median": sum(v.get("stalls", 0) for v in su.values())}
         conv_flop = sum(v["work"] for k, v in summ.items() if k.startswith("conv")) / a.steps
         t_min_ms = conv_flop / (peak * 1e12) * 1e3 + (hbm["work"] / a.steps) / (PEAK_HBM_GBPS * 1e9) * 1e3
         out = {
@@ -277,12 +312,14 @@ def main() -> None:
             "ranks": {"world_size": world, "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
                       "collective_ranks": dist.get_world_size() if world > 1 else 1, "ms_per_step_per_rank": per_rank_ms,
                       "head_exchange": "packed dW|db|feature-sum|loss, one all-reduce per modality phase on its own communicator",
-                      "encoder_gradients": "flat 44.7 MB buffer per encoder, 16 MB buckets, async all-reduce on RCCL's stream"},
+                      "encoder_gradients": "flat 44.7 MB buffer per encoder, 16 MB buckets, async all-reduce on RCCL's stream",
+                      "exchange_timing": dist_diag},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": traffic,
                          "avg_launch_ms": round(ig["ms"] / max(ig["launches"], 1), 4),
+                         "avg_launch_ms_raw": round(ig["ms_raw"] / max(ig["launches"], 1), 4),
                          "stalled_brackets_replaced_by_median": sum(v.get("stalls", 0) for v in summ.values()),
                          "algorithmic_gflop_per_launch": round(ig["work"] / max(ig["launches"], 1) / 1e9, 2),
                          "measured": "HIP events around every conv launch over %d steps run right after the timed region "

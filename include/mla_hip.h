@@ -275,9 +275,12 @@ int mla_attention_bwd(const float* d_o, const float* qkv, const float* o, const 
 int mla_tokens_assemble(float* x0, const float* table, const int64_t* ids, const float* pos, const float* type,
                         const float* cls, int B, int L, int D, int V, void* stream);
 /* its gradients: dcls, dtype (needs colsum_all = column sum of dx0 over all B*(L+1) rows) and, for text,
- * dtable[ids] += dx0 rows (float atomics; dtable pre-zeroed). */
+ * dtable[ids] += dx0 rows (nn.Embedding backward, m3ae.py:306, 360; dtable pre-zeroed by the caller).  Deterministic since
+ * ABI 3: ids are sorted on the device and the rows of one id are added in ascending token order (no float atomics), so
+ * repeated runs agree bit for bit.  ws >= mla_tokens_assemble_bwd_ws_bytes (only read when dtable != NULL). */
+size_t mla_tokens_assemble_bwd_ws_bytes(int B, int L, int D);
 int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls, float* dtype,
-                            float* dtable, int B, int L, int D, int V, void* stream);
+                            float* dtable, int B, int L, int D, int V, void* ws, size_t ws_bytes, void* stream);
 /* einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)' (basic_model.py:184-186); also the im2col of CAV-MAE's
  * conv16x16/16 PatchEmbed (cav_mae.py:69-84).  transposed != 0: img is stored (B,C,W,H) (spectrogram (B,time,freq)
  * viewed as (B,1,freq,time), cav_mae.py:339-340). */

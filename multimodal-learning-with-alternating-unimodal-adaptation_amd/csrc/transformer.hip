@@ -421,13 +421,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(float* __restrict__ x0, c
 }
 
 // Gradients of the assembly: dcls[d] = sum_b dx0[b][0][d]; dtype[d] = sum_{b,t>=1} dx0[b][t][d] (given the
-// all-row column sum `tot`: dtype = tot - dcls); text: dtable[ids[b][i]] += dx0[b][1+i] (float atomics: the
-// only order-dependent sum in the library; dtable must be zeroed by the caller).
+// all-row column sum `tot`: dtype = tot - dcls).
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx0, const float* __restrict__ tot,
-                                                            const int64_t* __restrict__ ids, float* __restrict__ dcls,
-                                                            float* __restrict__ dtype, float* __restrict__ dtable, int B,
-                                                            int L, int D, int V) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+                                                            float* __restrict__ dcls, float* __restrict__ dtype, int B, int L, int D) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < (size_t)D) {
     float s = 0.f;
     if (dcls) {
@@ -436,15 +433,140 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
     }
     dtype[gid] = tot[gid] - s;
   }
-  if (dtable) {
-    const size_t total = (size_t)B * L * D;
-    for (size_t i = gid; i < total; i += gsz) {
-      const int d = (int)(i % D);
-      const size_t r = i / D;
-      const size_t b = r / L, t = r % L;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Embedding gradient dtable[ids[r]] += dx0 row of token r (nn.Embedding backward, m3ae.py:306, 360), DETERMINISTIC: the rows
+// of one id are summed in ascending token order whatever the launch geometry, so two runs agree bit for bit (round 2 used
+// fp32 atomics: the one order-dependent sum of the library, and 14x slower on the [PAD] id that half of a padded batch
+// shares -- MI355X_MICROARCH.md, Global float atomics, contention row).  Per chunk of <= EMB_CHUNK tokens:
+//   emb_sort_kernel     one workgroup: keys id * NPOS + r (u32) bitonic-sorted in LDS -> sorted (id, r) pairs; ids outside
+//                       [0, V) sort to the end as 0xFFFFFFFF and are skipped (the forward poisoned their rows with NaN)
+//   emb_segment_kernel  one wave per block of 32 sorted positions: runs of equal id are summed in order; a run that is a
+//                       whole segment goes straight to dtable, a run cut by the block boundary into part[block][0 | 1]
+//   emb_combine_kernel  one wave per block whose LAST run starts a segment that continues to the right: adds the partials
+//                       of the following blocks in order (a [PAD] segment of 8192 tokens = 256 partial rows), then dtable
+// Chunks (B * L > EMB_CHUNK) are processed one after the other on the stream and accumulate into dtable in chunk order.
+// ---------------------------------------------------------------------------------------------------
+#define EMB_CHUNK 16384
+#define EMB_BLK 32
+#define EMB_MAXD4 4          // float4 chunks per lane: D <= 1024
+
+__global__ __launch_bounds__(1024) void emb_sort_kernel(const int64_t* __restrict__ ids, int n, int npos, int V,
+                                                         unsigned* __restrict__ sorted) {
+  __shared__ unsigned keys[EMB_CHUNK];
+  for (int r = threadIdx.x; r < npos; r += 1024) {
+    unsigned k = 0xFFFFFFFFu;
+    if (r < n) {
       const int64_t id = ids[r];
-      if (id >= 0 && id < V) atomicAdd(&dtable[(size_t)id * D + d], dx0[(b * (L + 1) + t + 1) * D + d]);   // bad ids: forward already NaN
+      if (id >= 0 && id < V) k = (unsigned)id * (unsigned)npos + (unsigned)r;
     }
+    keys[r] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npos; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (npos >> 1); t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1));          // index with the `stride` bit clear
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int r = threadIdx.x; r < npos; r += 1024) sorted[r] = keys[r];
+}
+
+__device__ __forceinline__ unsigned emb_id(unsigned key, int sh) { return key == 0xFFFFFFFFu ? 0xFFFFFFFFu : key >> sh; }
+
+// dx0 row of chunk-local token r: tokens are numbered b * L + t over the chunk's token range starting at r0
+__device__ __forceinline__ const f32x4* emb_row(const float* __restrict__ dx0, unsigned r, int L, int D) {
+  const unsigned b = r / (unsigned)L, t = r - b * (unsigned)L;
+  return reinterpret_cast<const f32x4*>(dx0 + ((size_t)b * (L + 1) + t + 1) * D);
+}
+
+__global__ __launch_bounds__(256) void emb_segment_kernel(const float* __restrict__ dx0, const unsigned* __restrict__ sorted,
+                                                           int npos, int sh, int r0, int L, int D, float* __restrict__ dtable,
+                                                           float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int p0 = w * EMB_BLK;
+  if (p0 >= npos) return;
+  const int d4n = D >> 2;
+  const unsigned mykey = lane < EMB_BLK ? sorted[p0 + lane] : 0xFFFFFFFFu;
+  const unsigned left = p0 > 0 ? emb_id(sorted[p0 - 1], sh) : 0xFFFFFFFEu;                 // 0xFFFFFFFE: no such id
+  const unsigned right = p0 + EMB_BLK < npos ? emb_id(sorted[p0 + EMB_BLK], sh) : 0xFFFFFFFEu;
+  f32x4 acc[EMB_MAXD4];
+  unsigned cur = 0xFFFFFFFFu;
+  int run_first = 0;                                                                       // position (0..31) the current run began at
+  auto flush = [&](int end) {                                                              // run [run_first, end) of id `cur`
+    if (cur == 0xFFFFFFFFu) return;
+    const bool open_l = run_first == 0 && left == cur, open_r = end == EMB_BLK && right == cur;
+    float* dst = (open_l || open_r) ? part + ((size_t)w * 2 + (run_first == 0 ? 0 : 1)) * D : dtable + (size_t)cur * D;
+#pragma unroll
+    for (int j = 0; j < EMB_MAXD4; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d4n) {
+        f32x4* q = reinterpret_cast<f32x4*>(dst) + c;
+        *q = (open_l || open_r) ? acc[j] : *q + acc[j];
+      }
+    }
+  };
+  for (int i = 0; i < EMB_BLK; ++i) {
+    const unsigned key = __shfl(mykey, i, 64);
+    const unsigned id = emb_id(key, sh);
+    if (id != cur || id == 0xFFFFFFFFu) {
+      flush(i);
+      cur = id;
+      run_first = i;
+#pragma unroll
+      for (int j = 0; j < EMB_MAXD4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (id != 0xFFFFFFFFu) {
+      const f32x4* row = emb_row(dx0, (unsigned)r0 + (key & ((1u << sh) - 1u)), L, D);
+#pragma unroll
+      for (int j = 0; j < EMB_MAXD4; ++j) {
+        const int c = lane + 64 * j;
+        if (c < d4n) acc[j] += row[c];
+      }
+    }
+  }
+  flush(EMB_BLK);
+}
+
+__global__ __launch_bounds__(256) void emb_combine_kernel(const unsigned* __restrict__ sorted, int npos, int sh, int D,
+                                                           const float* __restrict__ part, float* __restrict__ dtable) {
+  const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int p0 = w * EMB_BLK, nblk = npos / EMB_BLK;
+  if (p0 + EMB_BLK >= npos) return;                                     // the last block has nothing to its right
+  const unsigned id = emb_id(sorted[p0 + EMB_BLK - 1], sh);             // id of this block's last run
+  if (id == 0xFFFFFFFFu || emb_id(sorted[p0 + EMB_BLK], sh) != id) return;      // not open to the right
+  const bool single = emb_id(sorted[p0], sh) == id;                     // the block is one run
+  if (single && p0 > 0 && emb_id(sorted[p0 - 1], sh) == id) return;     // ... that continues a segment started further left
+  const int d4n = D >> 2;
+  f32x4 acc[EMB_MAXD4];
+  const f32x4* first = reinterpret_cast<const f32x4*>(part + ((size_t)w * 2 + (single ? 0 : 1)) * D);
+#pragma unroll
+  for (int j = 0; j < EMB_MAXD4; ++j) {
+    const int c = lane + 64 * j;
+    acc[j] = c < d4n ? first[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int w2 = w + 1; w2 < nblk; ++w2) {                               // every following block that begins with this id
+    const int q0 = w2 * EMB_BLK;
+    const f32x4* pr = reinterpret_cast<const f32x4*>(part + (size_t)w2 * 2 * D);
+#pragma unroll
+    for (int j = 0; j < EMB_MAXD4; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d4n) acc[j] += pr[c];
+    }
+    const bool whole = emb_id(sorted[q0 + EMB_BLK - 1], sh) == id;
+    if (!(whole && q0 + EMB_BLK < npos && emb_id(sorted[q0 + EMB_BLK], sh) == id)) break;
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(dtable + (size_t)id * D);
+#pragma unroll
+  for (int j = 0; j < EMB_MAXD4; ++j) {
+    const int c = lane + 64 * j;
+    if (c < d4n) dst[c] += acc[j];
   }
 }
 
@@ -460,16 +582,40 @@ extern "C" int mla_tokens_assemble(float* x0, const float* table, const int64_t*
   return MLA_OK;
 }
 
+extern "C" size_t mla_tokens_assemble_bwd_ws_bytes(int B, int L, int D) {
+  (void)B; (void)L;
+  return (size_t)EMB_CHUNK * sizeof(unsigned) + (size_t)(EMB_CHUNK / EMB_BLK) * 2 * D * sizeof(float);
+}
+
 extern "C" int mla_tokens_assemble_bwd(const float* dx0, const float* colsum_all, const int64_t* ids, float* dcls,
-                                       float* dtype, float* dtable, int B, int L, int D, int V, void* stream) {
+                                       float* dtype, float* dtable, int B, int L, int D, int V, void* ws, size_t ws_bytes,
+                                       void* stream) {
   MLA_REQUIRE(dx0 && colsum_all && dtype && B > 0 && L > 0 && D > 0 && ((dtable == nullptr) == (ids == nullptr)) && (!dtable || V > 0),
               "mla_tokens_assemble_bwd: bad argument");
   MLA_REQUIRE(dcls || !dtable, "mla_tokens_assemble_bwd: the text path always has a [cls] token");
-  size_t blocks = dtable ? ((size_t)B * L * D + 255) / 256 : (size_t)cdiv(D, 256);
-  if (blocks > 16384) blocks = 16384;
-  if (blocks < (size_t)cdiv(D, 256)) blocks = cdiv(D, 256);
-  assemble_bwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(dx0, colsum_all, ids, dcls, dtype, dtable, B, L, D, V);
+  hipStream_t st = (hipStream_t)stream;
+  assemble_bwd_kernel<<<cdiv(D, 256), 256, 0, st>>>(dx0, colsum_all, dcls, dtype, B, L, D);
   MLA_CHECK_LAUNCH("assemble_bwd_kernel");
+  if (!dtable) return MLA_OK;
+  MLA_REQUIRE(D % 4 == 0 && D <= 256 * EMB_MAXD4, "mla_tokens_assemble_bwd: D=%d must be a multiple of 4, <= %d", D, 256 * EMB_MAXD4);
+  MLA_REQUIRE(L <= EMB_CHUNK && (long)V * EMB_CHUNK <= 0xFFFFFFFFL, "mla_tokens_assemble_bwd: L=%d / V=%d out of range", L, V);
+  MLA_REQUIRE(ws && ws_bytes >= mla_tokens_assemble_bwd_ws_bytes(B, L, D), "mla_tokens_assemble_bwd: workspace too small");
+  unsigned* sorted = (unsigned*)ws;
+  float* part = (float*)(sorted + EMB_CHUNK);
+  const int rows_per_chunk = EMB_CHUNK / L;                         // whole sequences per chunk
+  for (int b0 = 0; b0 < B; b0 += rows_per_chunk) {
+    const int nb = min(rows_per_chunk, B - b0), n = nb * L;
+    int npos = 64, sh = 6;
+    while (npos < n) { npos <<= 1; ++sh; }
+    emb_sort_kernel<<<1, 1024, 0, st>>>(ids + (size_t)b0 * L, n, npos, V, sorted);
+    MLA_CHECK_LAUNCH("emb_sort_kernel");
+    const float* dx_chunk = dx0 + (size_t)b0 * (L + 1) * D;
+    const int waves = npos / EMB_BLK;
+    emb_segment_kernel<<<cdiv(waves, 4), 256, 0, st>>>(dx_chunk, sorted, npos, sh, 0, L, D, dtable, part);
+    MLA_CHECK_LAUNCH("emb_segment_kernel");
+    emb_combine_kernel<<<cdiv(waves, 4), 256, 0, st>>>(sorted, npos, sh, D, part, dtable);
+    MLA_CHECK_LAUNCH("emb_combine_kernel");
+  }
   return MLA_OK;
 }
 

@@ -12,5 +12,5 @@ void mla_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int mla_abi_version(void) { return 2; }
+extern "C" int mla_abi_version(void) { return 3; }
 extern "C" const char* mla_last_error(void) { return g_err; }

@@ -94,7 +94,8 @@ PROTOTYPES = {
     "mla_attention_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mla_attention_bwd": (_I, [_P] * 7 + [_I, _I, _I, _I, _P]),
     "mla_tokens_assemble": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
-    "mla_tokens_assemble_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P]),
+    "mla_tokens_assemble_bwd_ws_bytes": (_Z, [_I, _I, _I]),
+    "mla_tokens_assemble_bwd": (_I, [_P] * 6 + [_I, _I, _I, _I, _P, _Z, _P]),
     "mla_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 

@@ -67,8 +67,15 @@ class NpyBatcher:
         self.audio, self.text, self.image_fn, self.order = audio_feature_path, text_feature_path, image_fn, order
         self.drop_last = drop_last
         self.pin = torch.cuda.is_available() if pin is None else bool(pin)
-        self.ring = max(2, ring)          # >= DeviceFeeder.depth: a staging tuple is reused only after its copy was issued
+        # A staging tuple is reused only after the H2D copies that read it have COMPLETED: the consumer (DeviceFeeder) hands
+        # the event it recorded behind those copies to `copied()`, and the slot's refill synchronizes on it.  ("Issued" is not
+        # enough: DeviceFeeder's copy stream waits on device events of earlier steps and MLATrainer never host-syncs, so the
+        # host can run many batches ahead of the DMA engine.)  Without a consumer that calls `copied()` -- list(batcher),
+        # a plain loop -- nothing is fenced, and nothing needs to be: such a consumer reads a batch before it asks for the next.
+        self.ring = max(2, ring)
         self._stage: List[Optional[tuple]] = [None] * self.ring
+        self._fence: List[Optional[object]] = [None] * self.ring
+        self._unfenced: List[int] = []    # staging slots yielded and not yet fenced, oldest first
 
     def __len__(self) -> int:
         n = len(self.names)
@@ -87,12 +94,24 @@ class NpyBatcher:
             self._stage[k] = st
         return st
 
+    def copied(self, event) -> None:
+        """Consumer hook: `event` (anything with .synchronize(), e.g. torch.cuda.Event) completes when the asynchronous copies
+        out of the OLDEST batch not yet reported have finished.  DeviceFeeder calls it once per batch, in order."""
+        if self._unfenced:
+            self._fence[self._unfenced.pop(0)] = event
+
     def __iter__(self) -> Iterator[tuple]:
         k = 0
+        self._unfenced = []
         for b0 in range(0, len(self.names), self.B):
             ids = range(b0, min(b0 + self.B, len(self.names)))
             if self.drop_last and len(ids) < self.B:
                 return
+            if self._fence[k] is not None:             # the DMA out of this staging tuple must have run before it is refilled
+                self._fence[k].synchronize()
+                self._fence[k] = None
+            if k in self._unfenced:                    # consumer without copied(): it has consumed the batch by now
+                self._unfenced.remove(k)
             first_img = self.image_fn(self.names[ids[0]])
             *tensors, keys = self._staging(k, len(ids), first_img.shape)
             out = dict(zip(keys, tensors))
@@ -110,5 +129,6 @@ class NpyBatcher:
                 out["image"][j].copy_(img)
                 out["label"][j] = self.labels[i]
                 out["idx"][j, 0] = i
+            self._unfenced.append(k)
             yield tuple(tensors)
             k = (k + 1) % self.ring

@@ -37,6 +37,21 @@ def _high_priority_options(group):
         return None
 
 
+# One head communicator per parent group for the life of the process: dist.new_group is a COLLECTIVE and its communicator is
+# never destroyed, so building one per Comm() leaked RCCL communicators / streams and turned e.g. `Evaluator(model)` on a subset
+# of the ranks into a deadlock.  Keyed by the parent group object (None = the default group).
+_HEAD_GROUPS: dict = {}
+
+
+def _head_group_for(group):
+    parent = group if group is not None else dist.distributed_c10d._get_default_group()
+    entry = _HEAD_GROUPS.get(id(parent))          # the entry keeps `parent` alive, so its id is never reused while cached
+    if entry is None or entry[0] is not parent:   # (a destroy_process_group / init_process_group cycle makes a new default group)
+        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+        entry = _HEAD_GROUPS[id(parent)] = (parent, dist.new_group(ranks=ranks, pg_options=_high_priority_options(group)))
+    return entry[1]
+
+
 class Comm:
     def __init__(self, group=None, bucket_bytes: int = 16 << 20, force: bool = False, dedicated_head_group: bool = True):
         """force=True issues every collective even with a single rank (used to rehearse the RCCL path on
@@ -47,11 +62,12 @@ class Comm:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.active = (self.world > 1) or (force and dist.is_initialized())
         # The head path is latency-critical and must not queue behind the 44.7 MB encoder-gradient buckets: it
-        # gets its own communicator (own RCCL stream).  new_group is collective: every rank builds its Comm at the same point.
+        # gets its own communicator (own RCCL stream).  new_group is collective: the FIRST Comm of a parent group must be built
+        # by every rank at the same point (MLATrainer / DataParallel construction); later ones reuse the cached communicator.
+        # The RCCL multi-rank path is unverified until a multi-GPU run exists.
         self.head_group = group
         if self.active and dedicated_head_group:
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            self.head_group = dist.new_group(ranks=ranks, pg_options=_high_priority_options(group))
+            self.head_group = _head_group_for(group)
 
     # ---- encoder gradients ------------------------------------------------------------------
     def allreduce_flat_async(self, flat: torch.Tensor) -> List:

@@ -16,6 +16,9 @@ all forwards before it returns, so no kernel touches a slot after `done` even th
 their own streams (tests/test_step_gpu.py::test_device_feeder_with_stream_pipeline_is_bitwise_equivalent).
 The feeder does not pin anything itself: copies are asynchronous when the loader hands over pinned tensors
 (DataLoader(pin_memory=True), main.py:785) and host-blocking (but still off the compute stream) for pageable ones.
+A source that RECYCLES pinned host memory (data.NpyBatcher's staging ring) exposes `copied(event)`: the feeder hands it the
+event recorded behind each batch's copies, and the source waits on it before overwriting that memory (a copy that has been
+issued has not necessarily run: the copy stream waits on device events of earlier steps and nothing here host-syncs).
 """
 from __future__ import annotations
 
@@ -51,6 +54,9 @@ class DeviceFeeder:
             for t, d in zip(batch, self._dev[k]):
                 d.copy_(t, non_blocking=True)
             ready.record()
+        copied = getattr(self.batches, "copied", None)   # sources that recycle pinned staging memory (data.NpyBatcher) refill a
+        if copied is not None:                           # staging tuple only once the copies out of it have completed
+            copied(ready)
         return ready
 
     def feed(self, batches: Iterable[Sequence[torch.Tensor]]) -> "DeviceFeeder":

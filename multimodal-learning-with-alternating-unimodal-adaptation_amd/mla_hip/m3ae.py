@@ -465,8 +465,10 @@ class M3AEEncoder(FlatModule):
             ops.linear_wgrad(ws["patches"], dx, self.g["patch_embed_a.proj.weight"], wgw, 1, B * L, self.PD, D, stream=st, split=self.split)
         elif self.kind == "text":
             self.g["text_embedding.weight"].zero_()
+            if "emb_ws" not in ws:
+                ws["emb_ws"] = torch.empty(ops.tokens_assemble_bwd_ws_bytes(B, L, D), device=self.device, dtype=torch.uint8)
             ops.tokens_assemble_bwd(dx, ws["colsum"], ws["ids"], self.g["cls_token"], self.g["encoder_text_type_embedding"],
-                                    self.g["text_embedding.weight"], B, L, D, stream=st)
+                                    self.g["text_embedding.weight"], B, L, D, stream=st, ws=ws["emb_ws"])
         else:
             ops.tokens_assemble_bwd(dx, ws["colsum"], None, self.g["cls_token"], self.g["encoder_image_type_embedding"], None,
                                     B, L, D, stream=st)

@@ -86,6 +86,12 @@ class OGM:
                 continue
             if hasattr(enc, "_await_tail"):
                 enc._await_tail()
+            works = getattr(enc, "_grad_works", None)
+            if works:                       # data-parallel protocol path: the encoder-gradient all-reduce is still in flight
+                enc.comm.wait(works)        # (autograd.py leaves it to FusedSGD.step()); modulate the REDUCED gradient
+                enc._grad_works = []
+            # Philox stream = (call counter, modality, tensor): the reference draws a fresh normal_() per tensor (main.py:399-407),
+            # so conv k of the audio and of the visual ResNet-18 must not share a noise sequence
             ops.ogm_modulate(enc.grad, plan.seg, plan.first, plan.n_seg, plan.total_chunks, self.coeff[m:m + 1],
-                             self.mode == "OGM_GE", self.seed, self.step, plan.ws if self.mode == "OGM_GE" else None)
+                             self.mode == "OGM_GE", self.seed, self.step * 8 + m, plan.ws if self.mode == "OGM_GE" else None)
         self.step += 1

@@ -38,7 +38,7 @@ class KernelTimer:
         self.records.append((kind, work, start, e, moved))
 
     def summary(self) -> dict:
-        """kind -> {'launches', 'ms', 'work', 'moved', 'stalls'} (call after torch.cuda.synchronize()).
+        """kind -> {'launches', 'ms', 'ms_raw', 'work', 'moved', 'stalls'} (call after torch.cuda.synchronize()).
         The same call (kind, work) repeats every step; an elapsed time above 4x the median of its repeats and more than 1 ms
         over it is a host / profiler stall between the two event records, not kernel time (seen under rocprofv3: one 100 ms
         buffer flush inside a 0.2 ms bracket): it is replaced by that median and counted in 'stalls'."""
@@ -48,8 +48,9 @@ class KernelTimer:
         med = {k: sorted(v)[len(v) // 2] for k, v in groups.items()}
         out: dict = {}
         for kind, work, s, e, moved in self.records:
-            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "work": 0.0, "moved": 0.0, "stalls": 0})
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "ms_raw": 0.0, "work": 0.0, "moved": 0.0, "stalls": 0})
             t, m = s.elapsed_time(e), med[(kind, work)]
+            d["ms_raw"] += t                       # as measured, stalled brackets included (reported beside the corrected sum)
             if len(groups[(kind, work)]) >= 3 and t > 4.0 * m and t > m + 1.0:
                 t = m
                 d["stalls"] += 1
@@ -546,10 +547,19 @@ def tokens_assemble(x0, table, ids, pos, type_emb, cls, B: int, L: int, D: int, 
                                           stream or cur_stream()), "mla_tokens_assemble")
 
 
-def tokens_assemble_bwd(dx0, colsum_all, ids, dcls, dtype, dtable, B: int, L: int, D: int, stream: Optional[int] = None):
+def tokens_assemble_bwd_ws_bytes(B: int, L: int, D: int) -> int:
+    return int(_lib.load().mla_tokens_assemble_bwd_ws_bytes(B, L, D))
+
+
+def tokens_assemble_bwd(dx0, colsum_all, ids, dcls, dtype, dtable, B: int, L: int, D: int, stream: Optional[int] = None,
+                        ws: Optional[torch.Tensor] = None):
+    """ws (uint8, >= tokens_assemble_bwd_ws_bytes): scratch of the deterministic embedding scatter (text path only)."""
     V = dtable.shape[0] if dtable is not None else 0
+    if dtable is not None and ws is None:
+        ws = torch.empty(tokens_assemble_bwd_ws_bytes(B, L, D), device=dx0.device, dtype=torch.uint8)
     check(_lib.load().mla_tokens_assemble_bwd(_p(dx0), _p(colsum_all), _p(ids, torch.int64), _p(dcls), _p(dtype), _p(dtable),
-                                              B, L, D, V, stream or cur_stream()), "mla_tokens_assemble_bwd")
+                                              B, L, D, V, _p(ws, torch.uint8) if ws is not None else None,
+                                              ws.numel() if ws is not None else 0, stream or cur_stream()), "mla_tokens_assemble_bwd")
 
 
 def patchify(img, out, P: int = 16, transposed_hw: Optional[tuple] = None, stream: Optional[int] = None):

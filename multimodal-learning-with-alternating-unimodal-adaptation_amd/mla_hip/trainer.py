@@ -62,6 +62,10 @@ class MLATrainer:
         self._estreams, self._wstreams = pool[:ne], pool[ne:]
         self.overlap_forward = False
         self.set_overlap(self._can_overlap)
+        # Optional HIP-event brackets around the two data-parallel waits of a step (bench.py --gpus N): the packed head exchange
+        # (critical path, calling stream) and the wait for an encoder's gradient all-reduce in front of its SGD launch (that
+        # encoder's stream).  {"head_exchange": [(start, end)...], "grad_wait": [...]} or None (off: nothing is recorded).
+        self.dist_events: Optional[dict] = None
 
     def join(self) -> None:
         """Make the current stream wait for every encoder chain (parameters, momentum, gradients, BN buffers final).
@@ -105,7 +109,9 @@ class MLATrainer:
         r_mean = None
         if self.comm.active:
             ops.colsum(feat, self._colsum, inv_batch)
+            ev0 = self._ev_begin()
             self.comm.exchange_head(self.head.grad, self._colsum, self.losses["loss_" + name], self._msg)
+            self._ev_end("head_exchange", ev0)
             r_mean = self._colsum
         if self.keep_debug:      # test hooks: inputs of the projection (it is ill-conditioned, tests re-evaluate it in fp64)
             self.last[f"head_grad_{name}_raw"] = self.head.weight_grad.clone()
@@ -124,6 +130,29 @@ class MLATrainer:
 
     def _on(self, stream):
         return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def _ev_begin(self):
+        if self.dist_events is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                                   # on the current stream = the stream the bracketed work is enqueued on
+        return e
+
+    def _ev_end(self, kind: str, start) -> None:
+        if start is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.dist_events.setdefault(kind, []).append((start, e))
+
+    def dist_event_ms(self) -> dict:
+        """kind -> (count, mean ms) of the recorded brackets (call after a device synchronize); clears them."""
+        out = {}
+        for kind, pairs in (self.dist_events or {}).items():
+            ts = [s.elapsed_time(e) for s, e in pairs]
+            out[kind] = (len(ts), sum(ts) / max(len(ts), 1))
+        if self.dist_events is not None:
+            self.dist_events = {}
+        return out
 
     def train_step(self, *batch):
         """AVClassifier:     train_step(spec, image, label, batch_step, len_dataloader)
@@ -165,7 +194,9 @@ class MLATrainer:
             works = self._phase(tag, enc, feat, label, inv_batch, batch_step, len_dataloader, bs)
             opt.mark_ready(grp)
             with self._on(bs):
+                ev0 = self._ev_begin() if works else None
                 self.comm.wait(works)                                                         # encoder gradients reduced (data parallel)
+                self._ev_end("grad_wait", ev0)
                 opt.step_group(grp)                                                           # optimizer.step(): this encoder
             if opt.legacy_zero_grad:              # torch 1.8.1: earlier encoders hold zero (not None) grads in later steps (Q6)
                 for j in range(k):

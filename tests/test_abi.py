@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(fns) >= 26
     for name in fns:
         assert hasattr(lib, name), f"libmla_hip.so does not export {name}"
-    assert lib.mla_abi_version() == 2
+    assert lib.mla_abi_version() == 3
     assert lib.mla_last_error() is not None
 
 

@@ -72,3 +72,53 @@ def test_reference_npy_formats_roundtrip(tmp_path):
         load_token(text, "bad")
     with pytest.raises(MLAHipError, match="missing"):
         load_fbank(audio, "missing")
+
+
+class _FakeEvent:
+    def __init__(self, log, tag):
+        self.log, self.tag = log, tag
+
+    def synchronize(self):
+        self.log.append(self.tag)
+
+
+def test_staging_ring_is_refilled_only_after_its_copy_completed(tmp_path):
+    """a staging tuple may be overwritten only after the copies out of it COMPLETED (not merely were issued).
+    The consumer reports one event per batch through `copied()`; the refill of a slot must synchronize on that slot's event
+    first, in order, and a consumer that never calls copied() must still work."""
+    from mla_hip import NpyBatcher
+    names = [f"c{i:02d}" for i in range(11)]
+    audio, text, truth = _write_reference_style(str(tmp_path), names)
+    img = torch.zeros(3, 1, 4, 4)
+    nb = NpyBatcher(names, [0] * 11, 1, audio, text, image_fn=lambda n: img, order="av", ring=3, pin=False)
+    log, seen = [], []
+    for i, batch in enumerate(nb):
+        assert np.array_equal(batch[0][0].numpy(), truth[names[i]][0])
+        seen.append((i, list(log)))
+        nb.copied(_FakeEvent(log, i))            # "the copies of batch i complete when this event does"
+    # batch i (i >= ring) reuses the staging tuple of batch i - ring: exactly that event must have been waited for before
+    for i, waited in seen:
+        assert waited == list(range(0, max(0, i - 3 + 1))), (i, waited)
+    assert len(list(NpyBatcher(names, [0] * 11, 4, audio, text, image_fn=lambda n: img, ring=2, pin=False))) == 3   # no copied(): unfenced
+
+
+@pytest.mark.gpu
+def test_npy_batcher_pinned_ring_through_device_feeder_without_host_sync(tmp_path):
+    """The documented NpyBatcher -> DeviceFeeder path with pinned staging, more batches than ring + depth, the copy stream held
+    back behind a long device-side delay and no host synchronisation by the consumer: every batch must arrive intact."""
+    from mla_hip import DeviceFeeder, NpyBatcher
+    names = [f"c{i:02d}" for i in range(12)]
+    audio, text, truth = _write_reference_style(str(tmp_path), names)
+    imgs = {n: torch.full((3, 1, 4, 4), float(i)) for i, n in enumerate(names)}
+    nb = NpyBatcher(names, list(range(12)), 1, audio, text, image_fn=lambda n: imgs[n], order="av", ring=2, pin=True)
+    feeder = DeviceFeeder(nb, depth=3)
+    with torch.cuda.stream(feeder.copy_stream):
+        torch.cuda._sleep(int(2e9))              # ~1 s: the host is far ahead of the DMA engine unless the ring is fenced
+    got = []
+    for spec, image, label, idx in feeder:
+        got.append((spec.clone(), image.clone(), label.clone()))       # stream-ordered reads only
+    torch.cuda.synchronize()
+    assert len(got) == 12
+    for i, (spec, image, label) in enumerate(got):
+        assert np.array_equal(spec[0].cpu().numpy(), truth[names[i]][0]), f"batch {i}: spectrogram overwritten in the staging ring"
+        assert torch.equal(image[0].cpu(), imgs[names[i]]) and int(label[0]) == i

@@ -218,9 +218,12 @@ def _dump_report(name, obj):
         json.dump(obj, f, indent=1)
 
 
-PROJ_TOL_STEP0 = 3e-3     # measured 1.0e-3 ... 1.5e-3 (f32) / 1.2e-3 (split) against the fixture depending on last-bit differences of the
-                          # features (a 1e-6 relative feature perturbation moves this quantity by 1.7e-3), 3e-4 ... 4e-4 against fp64:
-                          # profiles/r02_m3ae_projection_errors_*.json
+PROJ_TOL_STEP0 = 2e-3     # = the largest value measured (1.5e-3: 1.0e-3 ... 1.5e-3 on f32, 1.2e-3 on split, depending on last-bit
+                          # differences of the features) + a 0.5e-3 margin.  The north star's 1e-3 is met only to within the
+                          # reference's own fp32 conditioning noise here: a 1e-6 relative feature perturbation moves this quantity by
+                          # 1.7e-3, CPU fp32 torch is itself 1.8e-4 ... 4.7e-4 from an fp64 evaluation of the same inputs, and the HIP
+                          # result is 3e-4 ... 4e-4 from fp64 on its own inputs (profiles/r02_m3ae_projection_errors_*.json);
+                          # every firing is additionally held to the fp64 criterion below.
 
 
 def test_assemble_patchify_avgpool(ops):
@@ -251,6 +254,24 @@ def test_assemble_patchify_avgpool(ops):
     assert_close(dtyp, dx0[:, 1:].sum((0, 1)), atol=2e-4, name="dtype")
     ref_tab = torch.zeros(V, D).index_add_(0, ids.reshape(-1), dx0[:, 1:].reshape(-1, D))
     assert_close(dtab, ref_tab, atol=1e-5, name="embedding scatter-add")
+    # deterministic (sorted ids, rows of one id added in token order): bit-identical on repetition, also for a batch that is
+    # half [PAD] (one id shared by thousands of tokens: a segment spanning many 32-row blocks), ids out of range skipped
+    B2, V2 = 40, 30522
+    ids2 = torch.from_numpy((O.portable_uniform(8, B2 * L, 3) * V2).astype(np.int64)).view(B2, L)
+    lens = torch.from_numpy((O.portable_uniform(9, B2, 3) * 249).astype(np.int64)) + 8
+    ids2[torch.arange(L)[None, :] >= lens[:, None]] = 0
+    ids2[3, 2], ids2[5, 0] = -1, V2                                              # nn.Embedding would assert: no gradient
+    dx2 = O.portable_normal(10, (B2, L + 1, D), stream=1).cuda()
+    runs = []
+    for _ in range(2):
+        dt = torch.zeros((V2, D), device="cuda")
+        ops.tokens_assemble_bwd(dx2, tot, ids2.cuda(), dcls, dtyp, dt, B2, L, D)
+        runs.append(dt)
+    assert torch.equal(runs[0], runs[1]), "embedding gradient must be bitwise reproducible"
+    ok = (ids2 >= 0) & (ids2 < V2)
+    ref2 = torch.zeros(V2, D, dtype=torch.float64).index_add_(0, ids2[ok], dx2.cpu()[:, 1:][ok].double())
+    assert_close(runs[0], ref2.float(), atol=2e-4, rtol=1e-5, name="embedding scatter-add, padded batch")
+    assert int((ids2 == 0).sum()) > 3000
     # patchify == einops 'b c (h p1) (w p2) -> b (h w) (c p1 p2)'
     img = O.portable_normal(6, (2, 3, 64, 48), stream=1)
     out = torch.empty((2 * 4 * 3, 768), device="cuda")
@@ -466,8 +487,8 @@ def test_modal3_three_way_alternation_vs_oracle():
 
 def test_full_size_config3_step_properties():
     """BASELINE configs[3] at its real size (Food-101: M3AE text + image, depth 12, batch 64, 101 classes) through one whole
-    step, without a CPU oracle: the stream pipeline equals the serialized trainer (bit for bit except the text embedding
-    table, whose scatter-add uses fp32 atomics), the two Linear arithmetics agree on logits / loss / raw head gradient
+    step, without a CPU oracle: the stream pipeline equals the serialized trainer bit for bit (the text embedding table
+    included: its scatter-add is deterministic since round 3), the two Linear arithmetics agree on logits / loss / raw head gradient
     within 2e-4, the fused attention agrees with the materialised one, everything stays finite."""
     from mla_hip import M3AEClassifier, MLATrainer
     B = 64
@@ -499,12 +520,134 @@ def test_full_size_config3_step_properties():
         del model, tr
         torch.cuda.empty_cache()
     a, b = out["f32_overlap"], out["f32_serial"]
-    for k in ("out_a", "out_v", "raw_a", "raw_v", "image", "head"):
+    for k in ("out_a", "out_v", "raw_a", "raw_v", "image", "head", "text"):     # text: the embedding scatter-add is deterministic
         assert torch.equal(a[k], b[k]), f"stream pipeline changed {k}"
-    assert_close(a["text"], b["text"], atol=1e-6, name="text encoder (atomic embedding scatter)")
     for other in ("split_overlap", "f32_materialized"):
         c = out[other]
         for k in ("out_a", "out_v", "raw_a", "raw_v"):
             assert_close(c[k], a[k], atol=2e-4, name=f"f32/fused vs {other}: {k} (B=64, depth 12)")
         for k in ("loss_a", "loss_v"):
             assert_close(c["loss"][k], a["loss"][k], atol=2e-4, name=f"f32/fused vs {other}: {k}")
+
+
+def test_full_size_config4_step_properties():
+    """BASELINE configs[4] at its real per-GPU size (IEMOCAP --modal3: CAV-MAE audio over 512 tokens + M3AE image + M3AE text,
+    depth 12, batch 32, 4 classes; models/basic_model.py:252-275, main.py:424, 455-466) through one whole three-way step a -> v -> t
+    without a CPU oracle (VERDICT r02 #1a): the stream pipeline equals the serialized trainer bit for bit (the text embedding
+    table included since the scatter-add is deterministic), the two Linear arithmetics agree on logits / loss / raw head gradients
+    within 2e-4, the fused attention agrees with the materialised one at n = 512 / 257, everything stays finite; and the
+    reference's own three-way loop, executed verbatim on the protocol objects at this size, reproduces the fused trainer.
+    The audio branch's arithmetic stays parity-unpinned (timm 0.4.5 absent): this test pins self-consistency, not the reference."""
+    import mla_hip
+    from mla_hip import Modal3Classifier, MLATrainer
+
+    class A:
+        fusion_method, dataset, gs_flag, modulation = "concat", "IEMOCAP", True, "Normal"
+    B = 32
+    g = torch.Generator(device="cuda").manual_seed(7)
+    token = torch.randint(0, 30522, (B, 1, 256), device="cuda", generator=g)
+    lens = torch.randint(8, 257, (B,), device="cuda", generator=g)
+    pm = (torch.arange(256, device="cuda")[None, :] >= lens[:, None]).float().view(B, 1, 256)
+    token[pm > 0] = 0                                                    # [PAD] = 0: thousands of tokens share one id
+    image = torch.randn((B, 3, 256, 256), device="cuda", generator=g)
+    spec = torch.randn((B, 1024, 128), device="cuda", generator=g) * 4.4849 - 5.081
+    label = torch.randint(0, 4, (B,), device="cuda", generator=g)
+    out = {}
+    for name, conv_math, overlap, attention in (("f32_overlap", "f32", True, "fused"), ("f32_serial", "f32", False, "fused"),
+                                                ("split_overlap", "split", True, "fused"), ("f32_materialized", "f32", True, "materialized")):
+        os.environ["MLA_ATTENTION"] = attention
+        try:
+            model = Modal3Classifier(A(), depth=12, seed=13, conv_math=conv_math)
+        finally:
+            os.environ.pop("MLA_ATTENTION", None)
+        tr = MLATrainer(model)
+        tr.keep_debug = True
+        tr.set_overlap(overlap)
+        losses = tr.train_step(token, pm, image, spec, label, 0, 100)
+        tr.join()
+        torch.cuda.synchronize()
+        assert tr.gs_plugin.exp_count == 3 and set(losses) == {"loss", "loss_a", "loss_v", "loss_t"}
+        out[name] = {"loss": {k: v.clone() for k, v in losses.items()}, "head": model.fusion_module.fc_out.flat.clone(),
+                     "audio": model.mae_a.flat.clone(), "image": model.mae_v.flat.clone(), "text": model.mae_t.flat.clone()}
+        for nm in ("a", "v", "t"):
+            out[name]["out_" + nm] = tr.last["out_" + nm].clone()
+            out[name]["raw_" + nm] = tr.last[f"head_grad_{nm}_raw"].clone()
+        for k in ("head", "audio", "image", "text"):
+            assert torch.isfinite(out[name][k]).all(), (name, k)
+        del model, tr
+        torch.cuda.empty_cache()
+    a, b = out["f32_overlap"], out["f32_serial"]
+    for k in ("out_a", "out_v", "out_t", "raw_a", "raw_v", "raw_t", "audio", "image", "text", "head"):
+        assert torch.equal(a[k], b[k]), f"stream pipeline changed {k}"
+    for other in ("split_overlap", "f32_materialized"):
+        c = out[other]
+        for k in ("out_a", "out_v", "out_t", "raw_a", "raw_v", "raw_t"):
+            assert_close(c[k], a[k], atol=2e-4, name=f"f32/fused vs {other}: {k} (B=32, depth 12)")
+        for k in ("loss_a", "loss_v", "loss_t"):
+            assert_close(c["loss"][k], a["loss"][k], atol=2e-4, name=f"f32/fused vs {other}: {k}")
+    # ---- the reference's three-way loop (main.py:424, 432-466, 468-470), verbatim, on the protocol objects at this size
+    class args:
+        lorb, modal3, clip = "m3ae", True, False
+    model = mla_hip.DataParallel(Modal3Classifier(A(), depth=12, seed=13, conv_math="f32"), device_ids=[0])
+    optimizer = mla_hip.FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    gs_plugin = mla_hip.GSPlugin()
+    criterion = mla_hip.CrossEntropyLoss()
+    padding_mask, batch_step, len_dataloader = pm, 0, 100
+    model.train()
+    optimizer.zero_grad()
+    if args.lorb == "large":
+        a, v = model(spec, image)
+    elif args.lorb == "m3ae":
+        if args.modal3:
+            a, v, t = model(token, padding_mask, image, spec)
+        else:
+            a, v = model(token, padding_mask, image)
+    out_a = model.module.fusion_module.fc_out(a)
+
+    loss_a = criterion(out_a, label)
+    loss_a.backward()
+
+    gs_plugin.before_update(model.module.fusion_module.fc_out, a,
+                            batch_step, len_dataloader, gs_plugin.exp_count)
+    optimizer.step()
+    optimizer.zero_grad()
+
+    gs_plugin.exp_count += 1
+
+    out_v = model.module.fusion_module.fc_out(v)
+
+    loss_v = criterion(out_v, label)
+    loss_v.backward()
+
+    gs_plugin.before_update(model.module.fusion_module.fc_out, v,
+                            batch_step, len_dataloader, gs_plugin.exp_count)
+    optimizer.step()
+    optimizer.zero_grad()
+
+    gs_plugin.exp_count += 1
+    if args.modal3:
+        out_t = model.module.fusion_module.fc_out(t)
+
+        loss_t = criterion(out_t, label)
+        loss_t.backward()
+
+        gs_plugin.before_update(model.module.fusion_module.fc_out, t,
+                                batch_step, len_dataloader, gs_plugin.exp_count)
+        optimizer.step()
+        optimizer.zero_grad()
+
+        gs_plugin.exp_count += 1
+
+    for n, p in model.named_parameters():
+        if p.grad != None:
+            del p.grad
+    torch.cuda.synchronize()
+    ref = out["f32_serial"]
+    for nm, o, l in (("a", out_a, loss_a), ("v", out_v, loss_v), ("t", out_t, loss_t)):
+        assert_close(o, ref["out_" + nm], atol=1e-5, name=f"verbatim loop vs trainer: logits {nm}")
+        assert abs(l.item() - ref["loss"]["loss_" + nm].item()) < 1e-5, nm
+    m = model.module
+    for k, enc in (("audio", m.mae_a), ("image", m.mae_v), ("text", m.mae_t)):
+        assert_close(enc.flat, ref[k], atol=2e-6, name=f"verbatim loop vs trainer: {k} encoder after the step")
+    assert_close(m.fusion_module.fc_out.flat, ref["head"], atol=5e-5, name="verbatim loop vs trainer: head after three phases")
+    assert gs_plugin.exp_count == 3 and gs_plugin.Pl.shape == (768, 768)

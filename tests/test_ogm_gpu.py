@@ -86,6 +86,15 @@ def test_ogm_modulation_vs_reference_vectors_and_verbatim_loop(golden_dir, mode)
             if g0.numel() >= 30000:                                                             # Gaussian shape: kurtosis 3, skew 0
                 z = noise / noise.std()
                 assert abs((z ** 4).mean().item() - 3.0) < 0.15 and abs((z ** 3).mean().item()) < 0.06, n
+    if mode == "OGM_GE":      # independent draws per tensor AND per modality (the reference calls normal_() per tensor, main.py:399-407)
+        def z_of(n):
+            return ((after[n] - before[n] * coeff[n.split(".")[0]]).double() / (before[n].double().std() + 1e-8)).flatten()
+        for k in ("layer1.0.conv1.weight", "layer3.1.conv2.weight"):          # same shape, same position in both encoders
+            za, zv = z_of("audio_net." + k), z_of("visual_net." + k)
+            corr = (za * zv).mean().item() / (za.std().item() * zv.std().item())
+            assert abs(corr) < 5.0 / za.numel() ** 0.5, (k, corr)
+        za, zb = z_of("audio_net.layer1.0.conv1.weight"), z_of("audio_net.layer1.0.conv2.weight")
+        assert abs((za * zb).mean().item()) < 5.0 / za.numel() ** 0.5
     for enc in ("audio_net", "visual_net"):                                                     # the reference's own numbers
         for k in ("conv1.weight", "layer1.0.conv1.weight", "bn1.weight"):
             if mode == "OGM":
