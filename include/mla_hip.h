@@ -113,6 +113,23 @@ int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw_hwio,
                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            void* ws, size_t ws_bytes, void* stream);
 int mla_conv2d_split_terms(int terms);
+/* The ResNet stem (backbone.py:79-83, 149: 7x7, stride 2, pad 3, 1 or 3 -> 64 channels) on the split arithmetic, as persistent
+ * patch-loader kernels: a workgroup keeps the weights (forward: three bf16 planes) resident in LDS, loads the 37 x 37 x Cin
+ * input patch of a 16 x 16 output tile once and serves all 49 taps from it.  `w` / `dw` are the plain fp32 HWIO weights (the
+ * forward splits them in its prologue).  mla_conv2d_stem_supported() != 0 for the shapes these entries accept; everything else
+ * (and conv_math = f32) runs on mla_conv2d_fwd / mla_conv2d_wgrad.  bn_partial as in mla_conv2d_fwd, fp64 partials, one row per
+ * workgroup (>= mla_conv2d_stem_fwd_partial_elems() floats); *bn_tiles receives the row count for mla_bn_finalize. */
+int mla_conv2d_stem_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
+/* measurement hook: force 4 or 8 waves per stem-forward workgroup, 0 = automatic (4 for Cin = 1, 8 for Cin = 3); other values: query */
+int mla_conv2d_stem_waves(int waves);
+size_t mla_conv2d_stem_fwd_partial_elems(void);
+int mla_conv2d_stem_fwd_split(const float* x, const float* w_hwio, float* y,
+                              int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                              float* bn_partial, int* bn_tiles, void* stream);
+size_t mla_conv2d_stem_wgrad_split_ws_bytes(int Cin);
+int mla_conv2d_stem_wgrad_split(const float* x, const float* dy, float* dw_hwio,
+                                int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                void* ws, size_t ws_bytes, void* stream);
 /* measurement hook: force tile 0..4 (256x128, 128x128, 128x64, 64x64, 256x64) where Cout allows; -1 = automatic */
 int mla_conv2d_split_cfg(int cfg);
 

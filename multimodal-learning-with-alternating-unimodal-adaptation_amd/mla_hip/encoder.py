@@ -14,7 +14,8 @@ MI355X-first host design, not a module-by-module port:
     convs (default "split", $MLA_CONV_MATH overrides):
     "f32" = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), "split" = fp32 operands split exactly into three bf16 terms,
     six products on v_mfma_f32_32x32x16_bf16 (fp32 in / out / accumulate, same error against fp64; the conv weights
-    are re-split once per forward).  The stem (1 / 3 input channels) always runs on the fp32 MFMA.
+    are re-split once per forward).  The stem (1 / 3 input channels) follows: persistent split-arithmetic kernels (stem_split.hip)
+    under "split", the fp32 MFMA under "f32".
 """
 from __future__ import annotations
 
@@ -78,6 +79,10 @@ class ResNet18Encoder(FlatModule):
             raise MLAHipError(f"conv_math must be 'f32' or 'split', got {self.conv_math!r}")
         self.device = torch.device(device)
         self.specs = conv_specs(modality)
+        # the stem follows conv_math too (round 3): "split" -> stem_split.hip's persistent kernels, "f32" -> the exact fp32 MFMA
+        # ($MLA_STEM_SPLIT=0: same-box A/B switch back to the fp32 stem under conv_math="split")
+        self.stem_split = (self.conv_math == "split" and os.environ.get("MLA_STEM_SPLIT", "1") != "0"
+                           and ops.conv2d_stem_supported(self.specs[0][1], self.specs[0][2], self.specs[0][3], self.specs[0][3], self.specs[0][4], self.specs[0][5]))
         # ---- flat layout: name -> (offset, shape); conv weights HWIO
         self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = 0
@@ -238,8 +243,8 @@ class ResNet18Encoder(FlatModule):
         ws["p0"] = torch.empty((N, hp, wp, 64), **f32)
         ws["pool_idx"] = torch.empty((N, hp, wp, 64), device=dev, dtype=torch.uint8)
         max_act = N * hp * wp * 64          # the stem's ReLU output / its gradient are never materialised (fused kernels)
-        max_partial = ops.conv2d_fwd_partial_elems(N, H, W, cin0, 64, 7, 7, 2, 3)
-        max_wgrad = ops.conv2d_wgrad_ws_bytes(N, H, W, cin0, 64, 7, 7, 2, 3)
+        max_partial = max(ops.conv2d_fwd_partial_elems(N, H, W, cin0, 64, 7, 7, 2, 3), ops.conv2d_stem_fwd_partial_elems())
+        max_wgrad = max(ops.conv2d_wgrad_ws_bytes(N, H, W, cin0, 64, 7, 7, 2, 3), ops.conv2d_stem_wgrad_split_ws_bytes(cin0))
         max_bnws = ops.bn_bwd_ws_elems(N * h1 * w1, 64)
         max_w = 0
         ch, cw, inpl = hp, wp, 64
@@ -345,18 +350,18 @@ class ResNet18Encoder(FlatModule):
         """p0 = maxpool(relu(bn1(conv1(x0)))): BN + ReLU are applied inside the max-pool, the (N,112,112,64)-sized ReLU
         output is never written (backbone.py:149-152)."""
         w = self.p["conv1.weight"]
-        wsp = self.wsp.get("conv1")
         x, y = ws["x0"], ws["y_stem"]
         ga, be = self.p["bn1.weight"], self.p["bn1.bias"]
+        stem_split = self.stem_split          # persistent split-arithmetic patch-loader kernel (stem_split.hip); else the fp32 MFMA
         if not self.training:
-            if wsp is not None:
-                ops.conv2d_fwd_split(x, wsp[0], w.shape, 2, 3, y=y, stream=st)
+            if stem_split:
+                ops.conv2d_stem_fwd_split(x, w, y=y, stream=st)
             else:
                 ops.conv2d_fwd(x, w, 2, 3, y=y, stream=st)
             ops.bn_relu_maxpool_fwd(y, self.rm["bn1"], self.rinv["bn1"], ga, be, ws["p0"], ws["pool_idx"], stream=st)
             return
-        if wsp is not None:
-            _, tiles = ops.conv2d_fwd_split(x, wsp[0], w.shape, 2, 3, y=y, bn_partial=ws["partial"], stream=st)
+        if stem_split:
+            _, tiles = ops.conv2d_stem_fwd_split(x, w, y=y, bn_partial=ws["partial"], stream=st)
         else:
             _, tiles = ops.conv2d_fwd(x, w, 2, 3, y=y, bn_partial=ws["partial"], stream=st)
         mean, invstd = ws["stats"]["bn1"]
@@ -455,6 +460,8 @@ class ResNet18Encoder(FlatModule):
         """Weight gradient of conv `name`; on the side stream when one is attached (after dy has been produced)."""
         side = self.wgrad_stream
         wgrad = ops.conv2d_wgrad_split if name in self.wsp else ops.conv2d_wgrad
+        if name == "conv1" and self.stem_split:
+            wgrad = ops.conv2d_stem_wgrad_split
         if side is None:
             wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
             return

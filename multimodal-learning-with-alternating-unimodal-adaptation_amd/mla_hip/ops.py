@@ -242,6 +242,59 @@ def conv2d_dgrad_split(dy: torch.Tensor, wsplit: torch.Tensor, w_shape, x_shape,
     return (dx, tiles.value) if nreq else dx
 
 
+def conv2d_stem_supported(Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int) -> bool:
+    """True where the persistent split-arithmetic stem kernels apply (7x7 / 2 / 3, 1 or 3 -> 64 channels)."""
+    return bool(_lib.load().mla_conv2d_stem_supported(Cin, Cout, KH, KW, stride, pad))
+
+
+def conv2d_stem_waves(waves: int = -1) -> int:
+    """Measurement hook: force 4 or 8 waves per stem-forward workgroup; 0 = automatic; -1: query."""
+    return int(_lib.load().mla_conv2d_stem_waves(int(waves)))
+
+
+def conv2d_stem_fwd_partial_elems() -> int:
+    return int(_lib.load().mla_conv2d_stem_fwd_partial_elems())
+
+
+def conv2d_stem_fwd_split(x: torch.Tensor, w_hwio: torch.Tensor, y: Optional[torch.Tensor] = None,
+                          bn_partial: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+    """The stem convolution (backbone.py:79-83, 149) on the split arithmetic, persistent patch-loader kernel; plain fp32 HWIO
+    weights.  Returns (y, partial rows) like conv2d_fwd."""
+    N, H, W, Cin = x.shape
+    KH, KW, Cin2, Cout = w_hwio.shape
+    if Cin2 != Cin:
+        raise MLAHipError(f"conv2d_stem_fwd_split: x has {Cin} channels, weight expects {Cin2}")
+    if y is None:
+        y = torch.empty((N, conv_out(H, KH, 2, 3), conv_out(W, KW, 2, 3), Cout), device=x.device, dtype=torch.float32)
+    if bn_partial is not None and bn_partial.numel() < conv2d_stem_fwd_partial_elems():
+        raise MLAHipError("conv2d_stem_fwd_split: bn_partial too small")
+    tiles = ctypes.c_int(0)
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_stem_fwd_split(_p(x), _p(w_hwio), _p(y), N, H, W, Cin, Cout, KH, KW, 2, 3, _p(bn_partial),
+                                                ctypes.addressof(tiles), stream or cur_stream()), "mla_conv2d_stem_fwd_split")
+    if t0 is not None:
+        TIMER.end("stem_fwd", 2.0 * y.numel() * KH * KW * Cin, t0)
+    return y, tiles.value
+
+
+def conv2d_stem_wgrad_split_ws_bytes(Cin: int) -> int:
+    return int(_lib.load().mla_conv2d_stem_wgrad_split_ws_bytes(Cin))
+
+
+def conv2d_stem_wgrad_split(x: torch.Tensor, dy: torch.Tensor, dw_hwio: torch.Tensor, stride: int, pad: int, ws: torch.Tensor,
+                            stream: Optional[int] = None) -> torch.Tensor:
+    """Stem weight gradient on the split arithmetic (same call shape as conv2d_wgrad)."""
+    N, H, W, Cin = x.shape
+    KH, KW, _, Cout = dw_hwio.shape
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_stem_wgrad_split(_p(x), _p(dy), _p(dw_hwio), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                  _p(ws), ws.numel() * ws.element_size(), stream or cur_stream()),
+          "mla_conv2d_stem_wgrad_split")
+    if t0 is not None:
+        TIMER.end("stem_wgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
+    return dw_hwio
+
+
 def conv2d_split_terms(terms: int = 0) -> int:
     """Select (3, 6, 8) or query (anything else) the bf16 product set of the split kernels; 6 = fp32-equivalent."""
     return int(_lib.load().mla_conv2d_split_terms(int(terms)))

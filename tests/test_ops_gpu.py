@@ -101,6 +101,91 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
 SPLIT_CASES = [c for c in CONV_CASES if c[3] % 64 == 0] + [(2, 33, 17, 128, 128, 3, 1, 1)]   # M = 1122: ragged vs every tile
 
 
+STEM_CASES = [
+    # N, H, W, Cin: the 7x7 / 2 / 3 stem (backbone.py:79-83) on the persistent split-arithmetic kernels (stem_split.hip)
+    (2, 40, 24, 1),        # audio, ragged tiles (OH x OW = 20 x 12)
+    (3, 36, 36, 3),        # visual, 18 x 18 outputs: one full + three partial tiles per image
+    (2, 128, 64, 1),       # smoke()-sized spectrogram: whole tiles only (64 x 32)
+    (5, 64, 64, 3),        # test-sized frames, 32 x 32 outputs
+    (1, 7, 9, 3),          # smaller than one tile, odd sizes
+    (70, 96, 33, 1),       # more tiles (70 x 3 x 2) than one round of some grids; odd width
+    (40, 224, 224, 3),     # real frame size: 1960 tiles > 256 workgroups: the persistent loop runs ~8 tiles per workgroup
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_stem_split_fwd_wgrad(ops, case):
+    """Stem forward (+ fused fp64 BatchNorm statistics) and weight gradient on the split arithmetic vs the oracle at the
+    tolerance of every other conv (2e-5 of max|ref|), vs the exact-fp32 stem kernels, bitwise reproducible, and -- like the
+    reference's convolution -- a non-finite input pixel only reaches the outputs whose 7x7 window contains it."""
+    N, H, W, Cin = case
+    seed = sum(case)
+    big = N * H * W * Cin > 2_000_000
+    x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
+    w = O.portable_normal(seed, (64, Cin, 7, 7), stream=2, std=math.sqrt(2.0 / (Cin * 49)))
+    xd, wd = nhwc(x).cuda(), hwio(w).cuda()
+    part = torch.zeros(ops.conv2d_stem_fwd_partial_elems(), device="cuda")
+    y, tiles = ops.conv2d_stem_fwd_split(xd, wd, bn_partial=part)
+    y32, _ = ops.conv2d_fwd(xd, wd, 2, 3)
+    torch.cuda.synchronize()
+    if big:        # the oracle takes minutes at this size: the exact-fp32 MFMA kernel (pinned to the oracle above) is the reference
+        y_ref = nchw(y32.cpu())
+    else:
+        y_ref = O.conv2d_fwd(x, w, 2, 3)
+        assert_close(nchw(y32.cpu()), y_ref, atol=0, rtol=2e-5, name="fp32 stem fwd")
+    assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="split stem fwd")
+    # statistics: per tile and lane fp32 sums of deviations from the lane's first value, folded into fp64 (stem_split.hip): compare
+    # with the fp64 sums of the stored y relative to sum |y| resp. sum y^2, and through the quantities BatchNorm forms from them
+    pt = part.view(torch.float64)[:tiles * 2 * 64].view(tiles, 2, 64).sum(0).cpu()
+    yd = y.double().cpu().reshape(-1, 64)
+    e0 = ((pt[0] - yd.sum(0)).abs() / yd.abs().sum(0)).max().item()
+    e1 = ((pt[1] - (yd ** 2).sum(0)).abs() / (yd ** 2).sum(0)).max().item()
+    assert e0 < 2e-6 and e1 < 2e-6, (e0, e1)
+    Mtot = yd.shape[0]
+    var_f, var_r = pt[1] / Mtot - (pt[0] / Mtot) ** 2, yd.var(0, unbiased=False)
+    assert ((var_f - var_r).abs() / var_r).max().item() < 1e-5, "batch variance from the fused statistics"
+    for wv in (4, 8):                       # both workgroup shapes give the same bits
+        ops.conv2d_stem_waves(wv)
+        y2, _ = ops.conv2d_stem_fwd_split(xd, wd)
+        assert torch.equal(y, y2), "stem forward must be bitwise reproducible (and independent of the statistics request / wave count)"
+    ops.conv2d_stem_waves(0)
+    # weight gradient
+    dy = O.portable_normal(seed, tuple(y_ref.shape), stream=3)
+    dyd = nhwc(dy).cuda()
+    dw = torch.empty((7, 7, Cin, 64), device="cuda")
+    ws = torch.empty(ops.conv2d_stem_wgrad_split_ws_bytes(Cin) // 4, device="cuda")
+    ops.conv2d_stem_wgrad_split(xd, dyd, dw, 2, 3, ws)
+    dw32 = torch.empty_like(dw)
+    ws32 = torch.empty(ops.conv2d_wgrad_ws_bytes(N, H, W, Cin, 64, 7, 7, 2, 3) // 4 + 4, device="cuda")
+    ops.conv2d_wgrad(xd, dyd, dw32, 2, 3, ws32)
+    torch.cuda.synchronize()
+    if big:
+        dw_ref = oihw(dw32.cpu())
+    else:
+        dw_ref = O.conv2d_wgrad(x, dy, w.shape, 2, 3)
+        assert_close(oihw(dw32.cpu()), dw_ref, atol=0, rtol=2e-5, name="fp32 stem wgrad")
+    assert_close(oihw(dw.cpu()), dw_ref, atol=0, rtol=2e-5, name="split stem wgrad")
+    dw2 = torch.empty_like(dw)
+    ops.conv2d_stem_wgrad_split(xd, dyd, dw2, 2, 3, ws)
+    assert torch.equal(dw, dw2), "stem weight gradient must be bitwise reproducible"
+    # window semantics: poison one pixel; exactly the outputs whose window covers it become non-finite
+    if not big:
+        n0, iy, ix = N - 1, H // 2, W // 2 + 1
+        xp = xd.clone()
+        xp[n0, iy, ix, Cin - 1] = float("inf")
+        yp, _ = ops.conv2d_stem_fwd_split(xp, wd)
+        bad = ~torch.isfinite(yp).all(dim=3).cpu()
+        want = torch.zeros_like(bad)
+        OH, OW = bad.shape[1], bad.shape[2]
+        for oy in range(OH):
+            for ox in range(OW):
+                if 0 <= iy - (2 * oy - 3) < 7 and 0 <= ix - (2 * ox - 3) < 7:
+                    want[n0, oy, ox] = True
+        assert torch.equal(bad, want), "an Inf input pixel must poison exactly the outputs whose window contains it"
+        good = ~want
+        assert torch.equal(yp.cpu()[good], y.cpu()[good])
+
+
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4], ids=lambda c: f"tile{c}")
 @pytest.mark.parametrize("case", SPLIT_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_split_fwd_dgrad(ops, case, cfg):
