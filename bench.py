@@ -263,7 +263,8 @@ def main() -> None:
             traffic_src = "profiles/" + os.path.basename(tpath) + " (PMC counters cannot be read inside this process; measured by " \
                           "separate rocprofv3 --pmc passes over this same command): " + tj["method"] + "; " + tj["note"]
         per_kind = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
-                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items() if k.startswith("conv")}
+                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in summ.items()
+                    if k.startswith("conv") or k.startswith("stem")}      # stem_*: the persistent split-arithmetic stem kernels (stem_split.hip)
         # HBM family: BatchNorm forward / backward against 8 TB/s; `achieved` = algorithmic bytes / time
         # the fused flow needs (forward 8-12 B/elem: the statistics come out of the conv epilogue; backward 12 B/elem where the
         # reduction pass runs in the input-gradient epilogue, 20 B/elem otherwise; stem: the ReLU output and its gradient are never
@@ -299,7 +300,7 @@ def main() -> None:
                                                     "GBps": round(survey_gb / (t_unf * 1e-3), 1),
                                                     "frac": round(survey_gb / (t_unf * 1e-3) / PEAK_HBM_GBPS, 4),
                                                     "stalled_brackets_replaced_by_median": sum(v.get("stalls", 0) for v in su.values())}
-        conv_flop = sum(v["work"] for k, v in summ.items() if k.startswith("conv")) / a.steps
+        conv_flop = sum(v["work"] for k, v in summ.items() if k.startswith("conv") or k.startswith("stem")) / a.steps
         t_min_ms = conv_flop / (peak * 1e12) * 1e3 + (hbm["work"] / a.steps) / (PEAK_HBM_GBPS * 1e9) * 1e3
         out = {
             "metric": "samples/sec per MLA alternating step, CREMA-D A+V bs=64",
@@ -327,7 +328,7 @@ def main() -> None:
                                      "region the encoder chains share the CUs" % (a.steps, dt_serial / a.steps * 1e3),
                          "traffic_source": traffic_src},
             "overlap": {"stream_pipeline": bool(overlapped), "ms_per_step_serialized_instrumented": round(dt_serial / a.steps * 1e3, 3),
-                        "conv_tflops_in_timed_region": round(sum(v["work"] for k, v in summ.items() if k.startswith("conv")) / dt / 1e12, 2)},
+                        "conv_tflops_in_timed_region": round(sum(v["work"] for k, v in summ.items() if k.startswith("conv") or k.startswith("stem")) / dt / 1e12, 2)},
             "roofline_hbm": hbm_roof,
             "step_vs_t_min": {"t_min_ms": round(t_min_ms, 2), "frac": round(t_min_ms / (dt / a.steps * 1e3), 4),
                               "definition": "T_min = conv FLOPs / MFMA peak + BN bytes / HBM peak (SURVEY 8d)"},
