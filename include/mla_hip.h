@@ -112,6 +112,9 @@ size_t mla_conv2d_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout, i
 int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw_hwio,
                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                            void* ws, size_t ws_bytes, void* stream);
+/* measurement hook: 0 = per-tap weight-gradient kernel for every layer, 1 (default) = the persistent all-taps kernel
+ * (transposing LDS reads) for the 64 -> 64 channel 3x3 / stride 1 convolutions; other values: query.  Returns the setting. */
+int mla_conv2d_wgrad_tr(int on);
 int mla_conv2d_split_terms(int terms);
 /* The ResNet stem (backbone.py:79-83, 149: 7x7, stride 2, pad 3, 1 or 3 -> 64 channels) on the split arithmetic, as persistent
  * patch-loader kernels: a workgroup keeps the weights (forward: three bf16 planes) resident in LDS, loads the 37 x 37 x Cin

@@ -1,0 +1,236 @@
+// Weight gradient of the 64 -> 64 channel 3x3 / stride 1 / pad 1 convolutions (ResNet-18 layer1, models/backbone.py:28, 31:
+// eight launches per step, the largest below-par block of round 2 at 113-128 TFLOP/s) on the split-bf16 arithmetic, as a
+// persistent all-taps kernel:  dW[t][ci][co] = sum over pixels  x[pixel + tap t][ci] * dy[pixel][co].
+//
+// wgrad_split_kernel (conv_igemm_split.hip) gives every (tap, pixel span) its own workgroup, so x and dy are gathered and split
+// nine times over and a 64 x 64 tile sees 16 FLOP per gathered byte.  Here one workgroup owns ALL NINE taps:
+//   * it walks 8 x 8-pixel output tiles; the 10 x 10 x 64 input patch and the 8 x 8 x 64 dy tile are loaded once, split once
+//     into three bf16 planes and stored in LDS in their NATURAL pixel-major layout ([channel half][pixel][32 channels], 64-B
+//     rows), double-buffered (the next tile is in flight in registers while this one computes);
+//   * the contraction runs over pixels, so both MFMA operands are the TRANSPOSE of those images: they are read with
+//     ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group reads 4 pixel rows x 16 channels and every lane
+//     receives 4 pixels of ITS channel).  A tap is then nothing but a different row address -- no im2col, no shifted copies,
+//     no alignment problem -- and the same dy fragments serve all nine taps of a step;
+//   * a wave keeps its 9 x (32 x 32) accumulators for the whole launch: one slab per workgroup at the end, then the ordered
+//     reduce of conv_igemm.hip (no atomics, bitwise reproducible).
+// 8 waves = 2 step groups x (2 ci blocks x 2 co blocks); a step = 16 pixels (two tile rows), 54 MFMAs per wave.
+#include "split_common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WT_TH = 8, WT_TW = 8;                      // output tile
+constexpr int WT_SW = WT_TW + 2, WT_SH = WT_TH + 2;      // input patch (halo 1)
+constexpr int WT_SPX = WT_SW * WT_SH;                    // 100 patch pixels
+constexpr int WT_TPX = WT_TH * WT_TW;                    // 64 tile pixels
+constexpr int WT_XPL = 2 * WT_SPX * 16;                  // dwords per x plane: [2 halves][100 px][16 dwords]
+constexpr int WT_YPL = 2 * WT_TPX * 16;                  // dwords per dy plane
+constexpr int WT_BUF = 3 * WT_XPL + 3 * WT_YPL;          // dwords per buffer (15744 = 61.5 KB)
+constexpr int WT_XU = (WT_SPX * 16 + 511) / 512;         // staging passes (512 float4 slots each) over the input patch: 4 (1600 slots)
+constexpr int WT_YU = WT_TPX * 16 / 512;                 // ... and over the dy tile: 2 (1024 slots)
+constexpr int WT_NLD = WT_XU + WT_YU;                    // float4 held per thread: 6
+constexpr int WT_RACC = 9 * 64 * 64;                     // floats of one slab
+
+struct WtGeom {
+  int N, H, W, tilesY, tilesX, ntiles;
+  unsigned x_bytes;
+};
+
+__device__ __forceinline__ unsigned wt_off_or_oob(int ok, unsigned off) { return off | ((unsigned)ok - 1u); }
+
+__device__ __forceinline__ s16x4 lds_tr(const unsigned* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad_tr_split_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                                 float* __restrict__ slabs, const WtGeom g) {
+  __shared__ __attribute__((aligned(16))) unsigned S[(2 * WT_BUF + 64 > WT_RACC ? 2 * WT_BUF + 64 : WT_RACC)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;     // step group, ci block, co block
+  const int i = lane & 31, h = lane >> 5;
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), yr = make_rsrc(dY, g.x_bytes);    // dy has the shape of x (64 -> 64, stride 1)
+
+  auto decode = [&](int t, int& n, int& oy0, int& ox0) {
+    const int per = g.tilesY * g.tilesX;
+    n = t / per;
+    const int rem = t - n * per;
+    const int ty = rem / g.tilesX;
+    oy0 = ty * WT_TH;
+    ox0 = (rem - ty * g.tilesX) * WT_TW;
+  };
+  // ---- staging: pass u < WT_XU covers float4 slot tid + 512 u of the input patch (pixel = slot >> 4, 4 channels = slot & 15;
+  // slots past 1600 are masked), pass u >= WT_XU slot tid + 512 (u - WT_XU) of the dy tile
+  f32x4 pre[WT_NLD];
+  auto stage_load = [&](int t) {
+    int n, oy0, ox0;
+    decode(t, n, oy0, ox0);
+#pragma unroll
+    for (int u = 0; u < WT_NLD; ++u) {
+      const bool isx = u < WT_XU;                                                // compile-time
+      const int sl = tid + 512 * (isx ? u : u - WT_XU);
+      const int px = sl >> 4, c4 = sl & 15;
+      const int wdt = isx ? WT_SW : WT_TW;
+      const int r = px / wdt, c = px - r * wdt;
+      const int iy = oy0 + r - (isx ? 1 : 0), ix = ox0 + c - (isx ? 1 : 0);     // the patch starts one pixel up / left of the tile
+      const int ok = (int)(px < (isx ? WT_SPX : WT_TPX)) & (int)((unsigned)iy < (unsigned)g.H) & (int)((unsigned)ix < (unsigned)g.W);
+      const unsigned off = ((unsigned)((n * g.H + iy) * g.W + ix) * 64u + (unsigned)c4 * 4u) * 4u;
+      pre[u] = buf_load4(isx ? xr : yr, wt_off_or_oob(ok, off), 0);
+    }
+  };
+  auto stage_store = [&](int buf, int u) {
+    const bool isx = u < WT_XU;
+    const int sl = tid + 512 * (isx ? u : u - WT_XU);
+    const int c4 = sl & 15;
+    int px = sl >> 4;
+    if (isx && px >= WT_SPX) px = WT_SPX - 1 + 0 * px;                          // masked slots (zeros) land on ... see below
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair<true>(pre[u][0], pre[u][1], h0, m0, l0);
+    split_pair<true>(pre[u][2], pre[u][3], h1, m1, l1);
+    const int npx = isx ? WT_SPX : WT_TPX, pl = isx ? WT_XPL : WT_YPL;
+    // image [half = c4 >> 3][pixel][(c4 & 7) * 2 dwords].  Patch slots past pixel 99 (pass 3, lanes of pixels 100..127) must not
+    // store: their pixel index is redirected to the scratch pixel row behind the dy planes (branch-free)
+    const bool live = !isx || (sl >> 4) < WT_SPX;
+    unsigned* dst = S + buf * WT_BUF + (isx ? 0 : 3 * WT_XPL) + ((c4 >> 3) * npx + px) * 16 + (c4 & 7) * 2;
+    if (!live) dst = S + 2 * WT_BUF + (tid & 31) * 2;                           // 64 scratch dwords after the two buffers
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(live ? dst + pl : dst) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(live ? dst + 2 * pl : dst) = u32x2{l0, l1};
+  };
+
+  // ---- transposing-read addressing (ds_read_b64_tr_b16): within a 16-lane group lane 4q + p supplies the address of pixel
+  // row q, channels 4p .. 4p+3 of the group's 16 channels; the group's lane c receives channel c of the 4 pixels.
+  // MFMA lanes 0-31 = 32 channels (two groups of 16), h = pixel half.  dwords: pixel row = 16 dwords, 16 channels = 8 dwords.
+  const int q = (lane & 15) >> 2, p = lane & 3, grp = (lane >> 4) & 1;
+  // A (x patch, channel half wi): step s of group sg covers tile rows 2 (2 sg + s) + h, pixels x = 0..7: lane pixel (row, q | q + 4)
+  // B (dy tile, channel half wj): tile pixel (2 (2 sg + s) + h) * 8 + q | q + 4
+  const int a_lane = (wi * WT_SPX + (2 * (2 * sg) + h + 1) * WT_SW + q + 1) * 16 + grp * 8 + p * 2;      // tap (0, 0), step 0, read 0
+  const int b_lane = 3 * WT_XPL + (wj * WT_TPX + (2 * (2 * sg) + h) * WT_TW + q) * 16 + grp * 8 + p * 2;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t9][e] = 0.f;
+
+  struct Fr { s16x4 lo[3], hi[3]; };                  // one operand fragment: pixels 0-3 | 4-7 of this lane's half, three planes
+  auto read_a = [&](const unsigned* Sc, int s, int t9, Fr& f) {      // compile-time s, t9
+    const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+    const unsigned* ap = Sc + a_lane + ((2 * s + dy) * WT_SW + dx) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      f.lo[pl] = lds_tr(ap + pl * WT_XPL);
+      f.hi[pl] = lds_tr(ap + pl * WT_XPL + 4 * 16);
+    }
+  };
+  auto read_b = [&](const unsigned* Sc, int s, Fr& f) {
+    const unsigned* bp = Sc + b_lane + (2 * s * WT_TW) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      f.lo[pl] = lds_tr(bp + pl * WT_YPL);
+      f.hi[pl] = lds_tr(bp + pl * WT_YPL + 4 * 16);
+    }
+  };
+  auto frag = [&](const Fr& f, int pl) {              // dword-granular: lets the register coalescer place lo | hi without moves
+    const u32x2 lo = __builtin_bit_cast(u32x2, f.lo[pl]), hi = __builtin_bit_cast(u32x2, f.hi[pl]);
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  for (int idx = tid; idx < 2 * WT_BUF; idx += 512) S[idx] = 0u;
+  int cur = 0;
+  int t = blockIdx.x;
+  if (t < g.ntiles) stage_load(t);
+  __syncthreads();
+  if (t < g.ntiles) {
+#pragma unroll
+    for (int u = 0; u < WT_NLD; ++u) stage_store(0, u);
+  }
+  __syncthreads();
+  constexpr int U = 2 * 9;                             // units of a tile for one wave: (step s, tap)
+  for (; t < g.ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    if (tn < g.ntiles) stage_load(tn);                 // in flight while this tile computes
+    const unsigned* Sc = S + cur * WT_BUF;
+    Fr a0, a1, b0, b1;
+    read_b(Sc, 0, b0);
+    read_a(Sc, 0, 0, a0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = u / 9, t9 = u - s * 9;
+      Fr& ac = (u & 1) ? a1 : a0;
+      Fr& an = (u & 1) ? a0 : a1;
+      Fr& bc = s ? b1 : b0;
+      if (u + 1 < U) read_a(Sc, (u + 1) / 9, (u + 1) % 9, an);
+      if (u == 4) read_b(Sc, 1, b1);                   // the second step's dy fragments, well ahead
+      if (u >= U - WT_NLD) stage_store(cur ^ 1, u - (U - WT_NLD));   // unconditional (stale registers without a next tile: never read)
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+        acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ac, TERM_A[term]), frag(bc, TERM_B[term]), acc[t9], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);          // the LDS reads of the next unit first
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- the two step groups' accumulators are summed in order through LDS; slab [9][64 ci][64 co] of this workgroup
+  float* R = reinterpret_cast<float*>(S);
+  for (int w = 0; w < 2; ++w) {
+    if (sg == w) {
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wi * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int o = (t9 * 64 + row) * 64 + wj * 32 + i;
+          if (w == 0) R[o] = acc[t9][e];
+          else slabs[(size_t)blockIdx.x * WT_RACC + o] = R[o] + acc[t9][e];
+        }
+    }
+    __syncthreads();
+  }
+}
+
+int wt_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
+
+}  // namespace
+
+int mla_wgrad_reduce(const float* part, float* dw, size_t n4, int splits, hipStream_t st);   // conv_igemm.hip
+
+// (not part of the C ABI: called by mla_conv2d_wgrad_split in conv_igemm_split.hip)
+bool mla_wgrad_tr_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  return Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && pad == 1;
+}
+size_t mla_wgrad_tr_ws_bytes() { return (size_t)wt_cus() * WT_RACC * sizeof(float); }
+
+int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
+  WtGeom g;
+  g.N = N; g.H = H; g.W = W;
+  g.tilesY = cdiv(H, WT_TH); g.tilesX = cdiv(W, WT_TW);
+  g.ntiles = N * g.tilesY * g.tilesX;
+  MLA_REQUIRE((size_t)N * H * W * 64 * 4 < 0xFFFFFFF0UL, "mla_conv2d_wgrad_split: tensors must be < 4 GiB");
+  g.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
+  const int grid = g.ntiles < wt_cus() ? g.ntiles : wt_cus();
+  const size_t need = (size_t)grid * WT_RACC * sizeof(float);
+  if (ws_bytes < need) {
+    mla_set_error("mla_conv2d_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
+    return MLA_ERR_WORKSPACE;
+  }
+  wgrad_tr_split_kernel<<<grid, 512, 0, st>>>(x, dy, (float*)ws, g);
+  MLA_CHECK_LAUNCH("wgrad_tr_split_kernel");
+  return mla_wgrad_reduce((const float*)ws, dw, (size_t)WT_RACC / 4, grid, st);
+}

@@ -295,6 +295,11 @@ def conv2d_stem_wgrad_split(x: torch.Tensor, dy: torch.Tensor, dw_hwio: torch.Te
     return dw_hwio
 
 
+def conv2d_wgrad_tr(on: int = -1) -> int:
+    """Measurement hook: 0 / 1 = per-tap / persistent all-taps split weight gradient for the 64 -> 64 3x3 convs; -1: query."""
+    return int(_lib.load().mla_conv2d_wgrad_tr(int(on)))
+
+
 def conv2d_split_terms(terms: int = 0) -> int:
     """Select (3, 6, 8) or query (anything else) the bf16 product set of the split kernels; 6 = fp32-equivalent."""
     return int(_lib.load().mla_conv2d_split_terms(int(terms)))

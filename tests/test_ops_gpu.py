@@ -101,6 +101,37 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
 SPLIT_CASES = [c for c in CONV_CASES if c[3] % 64 == 0] + [(2, 33, 17, 128, 128, 3, 1, 1)]   # M = 1122: ragged vs every tile
 
 
+@pytest.mark.parametrize("case", [(2, 20, 12), (3, 16, 8), (1, 8, 8), (5, 9, 11), (2, 56, 56), (64, 56, 24)], ids=lambda c: "x".join(map(str, c)))
+def test_wgrad_all_taps_tr_kernel(ops, case):
+    """Weight gradient of the 64 -> 64 channel 3x3 / 1 / 1 convolutions (layer1) by the persistent all-taps kernel
+    (wgrad_tr_split.hip: transposing LDS reads, every tap from one staged patch) vs the oracle / the per-tap kernel at the
+    conv tolerance, ragged tiles included, bitwise reproducible."""
+    N, H, W = case
+    seed = sum(case) + 7
+    big = N * H * W > 20000
+    x = O.portable_normal(seed, (N, 64, H, W), stream=1)
+    dy = O.portable_normal(seed, (N, 64, H, W), stream=3)
+    xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
+    ws = torch.empty(ops.conv2d_wgrad_split_ws_bytes(N, H, W, 64, 64, 3, 3, 1, 1) // 4 + 4, device="cuda")
+    assert ops.conv2d_wgrad_tr() == 1
+    dw = torch.empty((3, 3, 64, 64), device="cuda")
+    ops.conv2d_wgrad_split(xd, dyd, dw, 1, 1, ws)
+    dw_b = torch.empty_like(dw)
+    ops.conv2d_wgrad_split(xd, dyd, dw_b, 1, 1, ws)
+    ops.conv2d_wgrad_tr(0)
+    try:
+        dw_old = torch.empty_like(dw)
+        ops.conv2d_wgrad_split(xd, dyd, dw_old, 1, 1, ws)
+    finally:
+        ops.conv2d_wgrad_tr(1)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw_b), "bitwise reproducible"
+    ref = oihw(dw_old.cpu()) if big else O.conv2d_wgrad(x, dy, (64, 64, 3, 3), 1, 1)
+    if not big:
+        assert_close(oihw(dw_old.cpu()), ref, atol=0, rtol=2e-5, name="per-tap split wgrad")
+    assert_close(oihw(dw.cpu()), ref, atol=0, rtol=2e-5, name="all-taps split wgrad")
+
+
 STEM_CASES = [
     # N, H, W, Cin: the 7x7 / 2 / 3 stem (backbone.py:79-83) on the persistent split-arithmetic kernels (stem_split.hip)
     (2, 40, 24, 1),        # audio, ragged tiles (OH x OW = 20 x 12)
