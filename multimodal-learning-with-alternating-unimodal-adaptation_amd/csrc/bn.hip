@@ -259,6 +259,59 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const PT* __rest
   }
 }
 
+// ... and for MORE than BN_ONE_MAXT tiles (layer1: 2048 / 2352 conv tiles, the pooled stem backward): a block owns 4 channels x 64
+// tile lanes (lane k sums tiles k, k + 64, ...: <= 37 values at 2352 tiles, four loads in flight), combined through LDS in a fixed
+// order.  One launch instead of the stage-1 + finalize pair of round 2 (two dependent launches on the serial conv ->
+// statistics -> apply chain); bn_tiles_stage1_kernel / bn_finalize_kernel stay for tile counts beyond BN_WIDE_MAXT.
+#define BN_WIDE_MAXT 16384
+template <typename PT, int FWD>
+__global__ __launch_bounds__(256) void bn_finalize_tiles_wide_kernel(const PT* __restrict__ partial, int tiles, int M, int C, float eps,
+                                                                      float momentum, float* __restrict__ out0, float* __restrict__ out1,
+                                                                      float* running_mean, float* running_var) {
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, kl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    int t = kl;
+    for (; t + 192 < tiles; t += 256) {
+      const double a0 = (double)partial[((size_t)t * 2 + 0) * C + c], b0 = (double)partial[((size_t)t * 2 + 1) * C + c];
+      const double a1 = (double)partial[((size_t)(t + 64) * 2 + 0) * C + c], b1 = (double)partial[((size_t)(t + 64) * 2 + 1) * C + c];
+      const double a2 = (double)partial[((size_t)(t + 128) * 2 + 0) * C + c], b2 = (double)partial[((size_t)(t + 128) * 2 + 1) * C + c];
+      const double a3 = (double)partial[((size_t)(t + 192) * 2 + 0) * C + c], b3 = (double)partial[((size_t)(t + 192) * 2 + 1) * C + c];
+      s += (a0 + a1) + (a2 + a3);
+      q += (b0 + b1) + (b2 + b3);
+    }
+    for (; t < tiles; t += 64) {
+      s += (double)partial[((size_t)t * 2 + 0) * C + c];
+      q += (double)partial[((size_t)t * 2 + 1) * C + c];
+    }
+  }
+  red[0][kl][cl] = s;
+  red[1][kl][cl] = q;
+  __syncthreads();
+  if (kl != 0 || c >= C) return;
+  for (int k = 1; k < 64; ++k) {
+    s += red[0][k][cl];
+    q += red[1][k][cl];
+  }
+  if (FWD) {
+    const double m = s / M;
+    double var = q / M - m * m;
+    if (var < 0.0) var = 0.0;
+    out0[c] = (float)m;                                           // mean
+    out1[c] = (float)(1.0 / sqrt(var + (double)eps));             // invstd
+    if (running_mean) {
+      const double unb = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  } else {
+    out1[c] = (float)s;                                           // dbeta
+    out0[c] = (float)q;                                           // dgamma
+  }
+}
+
 // the one BN expression (explicit fma) every kernel that forms or re-forms bn(x) uses: identical rounding everywhere
 __device__ __forceinline__ f32x4 bn_val(const f32x4 x, const f32x4 mu, const f32x4 is, const f32x4 ga, const f32x4 be) {
   f32x4 r;
@@ -555,6 +608,11 @@ extern "C" int mla_bn_finalize(const float* partial, int tiles, int M, int C, fl
     MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
     return MLA_OK;
   }
+  if (tiles <= BN_WIDE_MAXT) {
+    bn_finalize_tiles_wide_kernel<double, 1><<<cdiv(C, 4), 256, 0, st>>>(pd, tiles, M, C, eps, momentum, mean, invstd, running_mean, running_var);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_wide_kernel");
+    return MLA_OK;
+  }
   double* scratch = const_cast<double*>(pd) + (size_t)tiles * 2 * C;
   const int S = bn_red_chunks(tiles);
   bn_tiles_stage1_kernel<double><<<dim3(cdiv(C, 64), S), 256, 0, st>>>(pd, tiles, C, scratch);
@@ -586,6 +644,9 @@ extern "C" int mla_bn_bwd(const float* dout, const float* relu_out, const float*
   if (nt <= BN_ONE_MAXT) {
     bn_finalize_tiles_kernel<float, 0><<<cdiv(C, 16), 256, 0, st>>>(ws, nt, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
     MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+  } else if (nt <= BN_WIDE_MAXT) {
+    bn_finalize_tiles_wide_kernel<float, 0><<<cdiv(C, 4), 256, 0, st>>>(ws, nt, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_wide_kernel");
   } else {
     double* scratch = reinterpret_cast<double*>(ws + (size_t)nt * 2 * C);
     const int S = bn_red_chunks(nt);
@@ -613,6 +674,9 @@ extern "C" int mla_bn_bwd_from_partial(const float* dout, const float* x, const 
   if (tiles <= BN_ONE_MAXT) {
     bn_finalize_tiles_kernel<float, 0><<<cdiv(C, 16), 256, 0, st>>>(partial, tiles, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
     MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+  } else if (tiles <= BN_WIDE_MAXT) {
+    bn_finalize_tiles_wide_kernel<float, 0><<<cdiv(C, 4), 256, 0, st>>>(partial, tiles, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_wide_kernel");
   } else {
     double* scratch = reinterpret_cast<double*>(partial + (size_t)tiles * 2 * C);
     const int S = bn_red_chunks(tiles);
@@ -656,6 +720,9 @@ extern "C" int mla_bn_bwd_pooled(const float* dpool, const uint8_t* idx, const f
   if (nt <= BN_ONE_MAXT) {
     bn_finalize_tiles_kernel<float, 0><<<cdiv(C, 16), 256, 0, st>>>(ws, nt, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
     MLA_CHECK_LAUNCH("bn_finalize_tiles_kernel");
+  } else if (nt <= BN_WIDE_MAXT) {
+    bn_finalize_tiles_wide_kernel<float, 0><<<cdiv(C, 4), 256, 0, st>>>(ws, nt, M, C, 0.f, 0.f, dgamma, dbeta, nullptr, nullptr);
+    MLA_CHECK_LAUNCH("bn_finalize_tiles_wide_kernel");
   } else {
     double* scratch = reinterpret_cast<double*>(ws + (size_t)nt * 2 * C);
     const int S = bn_red_chunks(nt);
