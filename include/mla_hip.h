@@ -115,6 +115,10 @@ int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw_hwio,
 /* measurement hook: 0 = per-tap weight-gradient kernel for every layer, 1 (default) = the persistent all-taps kernel
  * (transposing LDS reads) for the 64 -> 64 channel 3x3 / stride 1 convolutions; other values: query.  Returns the setting. */
 int mla_conv2d_wgrad_tr(int on);
+/* measurement / test hook: 0 = per-tap gather-GEMM for every layer, 1 (default; $MLA_CONV_PATCH overrides) = LDS-resident
+ * input patch (conv_patch_split.hip) for the 3x3 / stride 1 / pad 1 forward and input-gradient launches whose grid fills the chip,
+ * 2 = for all of them; other values: query.  Returns the setting. */
+int mla_conv2d_patch(int on);
 int mla_conv2d_split_terms(int terms);
 /* The ResNet stem (backbone.py:79-83, 149: 7x7, stride 2, pad 3, 1 or 3 -> 64 channels) on the split arithmetic, as persistent
  * patch-loader kernels: a workgroup keeps the weights (forward: three bf16 planes) resident in LDS, loads the 37 x 37 x Cin

@@ -14,6 +14,7 @@
 // the layout the MFMA B operand reads with one ds_read_b128) by mla_conv2d_wsplit; activations are split
 // in the kernel on their way from registers to LDS (v_cvt_pk_bf16_f32, ~5.5 VALU ops per element).
 #include "split_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 // LDS image of one operand plane: [rows][32 bf16] = 16 dwords per row, no padding; the 16-byte chunk q of row r
@@ -544,6 +545,28 @@ static int pick_scfg(long M, int CO, int weight, int k_total = 1 << 30) {
   return best;
 }
 
+// conv_patch_split.hip: 3x3 / stride 1 / pad 1 forward and input gradient with the A operand served from an LDS-resident patch
+bool mla_patch_supported(const IGemmGeom& g, bool force);
+int mla_patch_launch(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part, const IGemmGeom& g,
+                     int* bn_tiles, hipStream_t st);
+static int g_patch = -1;                              // -1: not yet read from $MLA_CONV_PATCH (default 1)
+static int patch_mode() {
+  if (g_patch < 0) {
+    const char* e = getenv("MLA_CONV_PATCH");
+    g_patch = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  }
+  return g_patch;
+}
+// measurement / test hook: 0 = per-tap gather-GEMM everywhere, 1 = default (patch kernel where its grid fills the chip), 2 = patch
+// kernel wherever the geometry allows; other values: query
+extern "C" int mla_conv2d_patch(int on) {
+  if (on >= 0 && on <= 2) g_patch = on;
+  return patch_mode();
+}
+static bool use_patch(const IGemmGeom& g) {
+  return patch_mode() && g_split_terms == 6 && g_split_cfg < 0 && mla_patch_supported(g, patch_mode() == 2);
+}
+
 template <int TERMS>
 static void launch_split_t(int cfg, int total, hipStream_t st, const float* X, const void* Wsp, float* Y, const float* R,
                            const float* MASK, float* part, const float* BIAS, float* Y2, const IGemmGeom& mg) {
@@ -595,6 +618,7 @@ extern "C" int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float*
   IGemmGeom g;
   make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
   MLA_REQUIRE(g.OH > 0 && g.OW > 0, "mla_conv2d_fwd_split: empty output");
+  if (use_patch(g)) return mla_patch_launch(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, bn_tiles, (hipStream_t)stream);
   const int cfg = pick_scfg(g.M, Cout, 1, KH * KW * Cin);
   if (bn_tiles) *bn_tiles = cdiv(g.M, scfg_bm(cfg));
   return launch_split(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, cfg, (hipStream_t)stream);
@@ -618,8 +642,14 @@ extern "C" int mla_conv2d_dgrad_split_bn(const float* dy, const void* wsplit, fl
       IGemmGeom g;
       make_dgrad_geom(g, py, px, N, H, W, Cin, Cout, KH, KW, stride, pad);
       if (g.M <= 0) continue;
-      const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1, KH * KW == 1 ? Cout : 1 << 30);
       if (int rc = attach_bn_reqs("mla_conv2d_dgrad_split_bn", g, reqs, nreq, tiles)) return rc;
+      if (use_patch(g)) {                               // stride 1: the one parity class is a 3x3 "same" convolution over dy
+        int ptiles = 0;
+        if (int rc = mla_patch_launch(dy, wsplit, dx, residual, relu_src, nullptr, g, &ptiles, (hipStream_t)stream)) return rc;
+        tiles += ptiles;
+        continue;
+      }
+      const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1, KH * KW == 1 ? Cout : 1 << 30);
       if (int rc = launch_split(dy, wsplit, dx, residual, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
       tiles += cdiv(g.M, scfg_bm(cfg));
     }

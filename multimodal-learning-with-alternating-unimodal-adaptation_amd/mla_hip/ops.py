@@ -300,6 +300,11 @@ def conv2d_wgrad_tr(on: int = -1) -> int:
     return int(_lib.load().mla_conv2d_wgrad_tr(int(on)))
 
 
+def conv2d_patch(on: int = -1) -> int:
+    """Measurement hook: 0 / 1 = per-tap gather-GEMM / LDS-patch kernel for the 3x3 stride-1 split forward and input gradient; -1: query."""
+    return int(_lib.load().mla_conv2d_patch(int(on)))
+
+
 def conv2d_split_terms(terms: int = 0) -> int:
     """Select (3, 6, 8) or query (anything else) the bf16 product set of the split kernels; 6 = fp32-equivalent."""
     return int(_lib.load().mla_conv2d_split_terms(int(terms)))

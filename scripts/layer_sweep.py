@@ -7,6 +7,10 @@ from mla_hip import ops
 from mla_hip.encoder import conv_specs
 math = os.environ.get("MATH", "split")
 B = int(os.environ.get("B", "64"))
+if "MLA_PATCH" in os.environ:                      # same-box A/B switches of the round-3 kernels
+    ops.conv2d_patch(int(os.environ["MLA_PATCH"]))
+if "MLA_WGRAD_TR" in os.environ:
+    ops.conv2d_wgrad_tr(int(os.environ["MLA_WGRAD_TR"]))
 
 
 def timeit(fn, rep=10):

@@ -132,6 +132,72 @@ def test_wgrad_all_taps_tr_kernel(ops, case):
     assert_close(oihw(dw.cpu()), ref, atol=0, rtol=2e-5, name="all-taps split wgrad")
 
 
+PATCH_CASES = [
+    # N, H, W, Cin, Cout: 3x3 / stride 1 / pad 1 (every BasicBlock conv but the three stride-2 ones, backbone.py:28, 31)
+    (2, 20, 12, 64, 64),      # layer1 shape class: BN = 64, two taps per K stage; M = 480: one full + one ragged 256-pixel tile
+    (2, 10, 6, 128, 128),     # BN = 128
+    (3, 7, 7, 256, 256),      # 7 x 7 maps: a tile spans five images (halo rows belong to other images)
+    (2, 4, 4, 512, 512),      # 16 chunks
+    (5, 32, 4, 64, 64),       # audio layer4-like narrow maps
+    (1, 5, 3, 64, 128),       # smaller than one tile, Cin != Cout
+    (3, 56, 56, 64, 64),      # visual layer1 rows: the widest patch (8 rows x 58 pixels)
+    (40, 14, 14, 256, 256),   # many tiles: the grid exceeds the CU count
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_patch_fwd_dgrad(ops, case):
+    """Forward (+ fused fp64 BatchNorm statistics) and input gradient (+ residual, ReLU mask) of the 3x3 / 1 / 1 convolutions
+    by the LDS-patch kernel (conv_patch_split.hip) vs the oracle / the per-tap gather-GEMM at the conv tolerance."""
+    N, H, W, Cin, Cout = case
+    seed = sum(case) + 3
+    big = N * H * W * max(Cin, Cout) > 1_500_000
+    x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
+    w = O.portable_normal(seed, (Cout, Cin, 3, 3), stream=2, std=math.sqrt(2.0 / (Cin * 9)))
+    xd, wd = nhwc(x).cuda(), hwio(w).cuda()
+    wT, wS = ops.conv2d_wsplit(wd, True), ops.conv2d_wsplit(wd, False)
+    default = ops.conv2d_patch()
+    assert default in (0, 1, 2)
+    part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, 3, 3, 1, 1), device="cuda")
+    ops.conv2d_patch(2)                       # the patch kernel wherever the geometry allows (by default only where its grid fills the chip)
+    try:
+        y, tiles = ops.conv2d_fwd_split(xd, wT, wd.shape, 1, 1, bn_partial=part)
+        y2, _ = ops.conv2d_fwd_split(xd, wT, wd.shape, 1, 1)
+        ops.conv2d_patch(0)
+        y_old, _ = ops.conv2d_fwd_split(xd, wT, wd.shape, 1, 1)
+    finally:
+        ops.conv2d_patch(default)
+    torch.cuda.synchronize()
+    assert tiles == (N * H * W + 255) // 256 and torch.equal(y, y2)
+    y_ref = nchw(y_old.cpu()) if big else O.conv2d_fwd(x, w, 1, 1)
+    if not big:
+        assert_close(nchw(y_old.cpu()), y_ref, atol=0, rtol=2e-5, name="per-tap fwd")
+    assert_close(nchw(y.cpu()), y_ref, atol=0, rtol=2e-5, name="patch fwd")
+    pt = part.view(torch.float64)[:tiles * 2 * Cout].view(tiles, 2, Cout).sum(0).cpu()
+    yd = y.double().cpu().reshape(-1, Cout)
+    assert_close(pt[0], yd.sum(0), atol=1e-6, rtol=1e-9, name="fused colsum == sums of the stored y")
+    assert_close(pt[1], (yd ** 2).sum(0), atol=1e-6, rtol=1e-9, name="fused colsumsq")
+    # input gradient with residual and ReLU mask
+    dy = O.portable_normal(seed, (N, Cout, H, W), stream=3)
+    res = O.portable_normal(seed, (N, Cin, H, W), stream=4)
+    msk = O.portable_normal(seed, (N, Cin, H, W), stream=5)
+    dyd, resd, mskd = nhwc(dy).cuda(), nhwc(res).cuda(), nhwc(msk).cuda()
+    ops.conv2d_patch(2)
+    try:
+        dx = ops.conv2d_dgrad_split(dyd, wS, wd.shape, xd.shape, 1, 1, residual=resd, relu_src=mskd)
+        ops.conv2d_patch(0)
+        dx_old = ops.conv2d_dgrad_split(dyd, wS, wd.shape, xd.shape, 1, 1, residual=resd, relu_src=mskd)
+    finally:
+        ops.conv2d_patch(default)
+    torch.cuda.synchronize()
+    if big:
+        dx_ref = nchw(dx_old.cpu())
+    else:
+        dx_ref = (O.conv2d_dgrad(dy, w, x.shape, 1, 1) + res) * (msk > 0)
+        assert_close(nchw(dx_old.cpu()), dx_ref, atol=0, rtol=2e-5, name="per-tap dgrad")
+    assert_close(nchw(dx.cpu()), dx_ref, atol=0, rtol=2e-5, name="patch dgrad")
+
+
 STEM_CASES = [
     # N, H, W, Cin: the 7x7 / 2 / 3 stem (backbone.py:79-83) on the persistent split-arithmetic kernels (stem_split.hip)
     (2, 40, 24, 1),        # audio, ragged tiles (OH x OW = 20 x 12)
