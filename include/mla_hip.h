@@ -107,6 +107,18 @@ int mla_conv2d_dgrad_bn(const float* dy, const float* w_hwio, float* dx, int N, 
 int mla_conv2d_dgrad_split_bn(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
                               int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
                               const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, void* stream);
+/* ... restricted to some output parity classes of a strided convolution (bit py * stride + px of class_mask; stride 1: bit 0),
+ * with `residual` added only in the classes of residual_mask.  Lets the 1x1 / stride-2 downsample input gradient
+ * (backbone.py:126-129) write just the one class it reaches, and the 3x3 / stride-2 conv1 beside it (backbone.py:28) accumulate
+ * onto it there, instead of a full read-modify-write pass over dx in four launches.  (0xF, 0xF) = the plain entry points. */
+int mla_conv2d_dgrad_classes(const float* dy, const float* w_hwio, float* dx, int N, int H, int W, int Cin, int Cout,
+                             int KH, int KW, int stride, int pad, const float* residual, const float* relu_src, float* wt_ws,
+                             const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, int class_mask, int residual_mask,
+                             void* stream);
+int mla_conv2d_dgrad_split_classes(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
+                                   int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
+                                   const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, int class_mask, int residual_mask,
+                                   void* stream);
 /* weight gradient on the same arithmetic (both operands split in the kernel); workspace and reduce as mla_conv2d_wgrad */
 size_t mla_conv2d_wgrad_split_ws_bytes(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw_hwio,

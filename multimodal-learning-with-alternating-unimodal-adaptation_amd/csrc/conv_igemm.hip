@@ -473,6 +473,14 @@ extern "C" int mla_conv2d_dgrad(const float* dy, const float* w, float* dx, int 
 extern "C" int mla_conv2d_dgrad_bn(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
                                    int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
                                    float* wt_ws, const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, void* stream) {
+  return mla_conv2d_dgrad_classes(dy, w, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, relu_src, wt_ws, reqs, nreq, bn_tiles,
+                                  0xF, 0xF, stream);
+}
+
+extern "C" int mla_conv2d_dgrad_classes(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
+                                        int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
+                                        float* wt_ws, const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, int class_mask,
+                                        int residual_mask, void* stream) {
   if (int rc = check_conv("mla_conv2d_dgrad", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
   MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_dgrad: Cin=%d must be a multiple of 64 (the stem needs no dgrad)", Cin);
   MLA_REQUIRE(dy && w && dx && wt_ws, "mla_conv2d_dgrad: null pointer");
@@ -485,6 +493,9 @@ extern "C" int mla_conv2d_dgrad_bn(const float* dy, const float* w, float* dx, i
   int tiles = 0;   // row tiles launched so far = first tile index of the next parity class in the BatchNorm partial buffers
   for (int py = 0; py < stride; ++py)
     for (int px = 0; px < stride; ++px) {
+      const int cls = py * stride + px;               // output parity class (py, px): bit of class_mask / residual_mask
+      if (!((class_mask >> cls) & 1)) continue;
+      const float* res = ((residual_mask >> cls) & 1) ? residual : nullptr;
       IGemmGeom g;
       make_dgrad_geom(g, py, px, N, H, W, Cin, Cout, KH, KW, stride, pad);
       const int T = g.T;
@@ -493,7 +504,7 @@ extern "C" int mla_conv2d_dgrad_bn(const float* dy, const float* w, float* dx, i
       const int wt = T > 0 ? T : 1;
       const int cfg = pick_cfg(&Mc, &wt, 1, Cin, false);
       if (int rc = attach_bn_reqs("mla_conv2d_dgrad_bn", g, reqs, nreq, tiles)) return rc;
-      if (int rc = launch_igemm(dy, wt_ws, dx, residual, relu_src, nullptr, g, false, cfg, st)) return rc;
+      if (int rc = launch_igemm(dy, wt_ws, dx, res, relu_src, nullptr, g, false, cfg, st)) return rc;
       tiles += cdiv(g.M, cfg_bm(cfg));
     }
   if (bn_tiles) *bn_tiles = tiles;

@@ -633,24 +633,35 @@ extern "C" int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float
 extern "C" int mla_conv2d_dgrad_split_bn(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
                                          int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
                                          const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, void* stream) {
+  return mla_conv2d_dgrad_split_classes(dy, wsplit, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, relu_src, reqs, nreq, bn_tiles,
+                                        0xF, 0xF, stream);
+}
+
+extern "C" int mla_conv2d_dgrad_split_classes(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
+                                              int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
+                                              const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, int class_mask,
+                                              int residual_mask, void* stream) {
   if (int rc = check_conv("mla_conv2d_dgrad_split", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
   MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_dgrad_split: Cin=%d must be a multiple of 64 (the stem needs no dgrad)", Cin);
   MLA_REQUIRE(dy && wsplit && dx, "mla_conv2d_dgrad_split: null pointer");
   int tiles = 0;
   for (int py = 0; py < stride; ++py)
     for (int px = 0; px < stride; ++px) {
+      const int cls = py * stride + px;               // output parity class (py, px): bit of class_mask / residual_mask
+      if (!((class_mask >> cls) & 1)) continue;
+      const float* res = ((residual_mask >> cls) & 1) ? residual : nullptr;
       IGemmGeom g;
       make_dgrad_geom(g, py, px, N, H, W, Cin, Cout, KH, KW, stride, pad);
       if (g.M <= 0) continue;
       if (int rc = attach_bn_reqs("mla_conv2d_dgrad_split_bn", g, reqs, nreq, tiles)) return rc;
       if (use_patch(g)) {                               // stride 1: the one parity class is a 3x3 "same" convolution over dy
         int ptiles = 0;
-        if (int rc = mla_patch_launch(dy, wsplit, dx, residual, relu_src, nullptr, g, &ptiles, (hipStream_t)stream)) return rc;
+        if (int rc = mla_patch_launch(dy, wsplit, dx, res, relu_src, nullptr, g, &ptiles, (hipStream_t)stream)) return rc;
         tiles += ptiles;
         continue;
       }
       const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1, KH * KW == 1 ? Cout : 1 << 30);
-      if (int rc = launch_split(dy, wsplit, dx, residual, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
+      if (int rc = launch_split(dy, wsplit, dx, res, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
       tiles += cdiv(g.M, scfg_bm(cfg));
     }
   if (bn_tiles) *bn_tiles = tiles;

@@ -41,6 +41,8 @@ PROTOTYPES = {
     "mla_conv2d_dgrad_bn_partial_elems": (_Z, [_I, _I, _I, _I]),
     "mla_conv2d_dgrad_bn": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P, _I, _P, _P]),
     "mla_conv2d_dgrad_split_bn": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _I, _P, _P]),
+    "mla_conv2d_dgrad_classes": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P, _I, _P, _I, _I, _P]),
+    "mla_conv2d_dgrad_split_classes": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _I, _P, _I, _I, _P]),
     "mla_conv2d_wgrad_split_ws_bytes": (_Z, [_I] * 9),
     "mla_conv2d_wgrad_split": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _Z, _P]),
     "mla_conv2d_wgrad_tr": (_I, [_I]),

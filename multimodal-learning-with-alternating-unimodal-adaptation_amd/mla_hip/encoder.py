@@ -36,6 +36,8 @@ from .module import BatchNorm2dHolder, Conv2dHolder, FlatModule
 DEFAULT_CONV_MATH = "split"
 # measurement switch (same-box A/B): 0 = every BatchNorm backward runs its own reduction pass (the round-1 / early round-2 flow)
 FUSE_BN_REDUCE = os.environ.get("MLA_FUSE_BN_REDUCE", "1") != "0"
+# measurement switch: 0 = the downsample input gradient is its own four-launch pass over dx (round 2)
+DS_DGRAD_FOLD = os.environ.get("MLA_DS_DGRAD_FOLD", "1") != "0"
 
 
 def conv_specs(modality: str) -> List[Tuple[str, int, int, int, int, int]]:
@@ -471,7 +473,8 @@ class ResNet18Encoder(FlatModule):
         with torch.cuda.stream(side):
             wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
 
-    def _dgrad(self, ws, st, dy, name, x_shape, stride, pad, dx, residual=None, relu_src=None, bn_next=()):
+    def _dgrad(self, ws, st, dy, name, x_shape, stride, pad, dx, residual=None, relu_src=None, bn_next=(), class_mask=0xF,
+               residual_mask=0xF):
         """Input gradient of conv `name`.  bn_next: [(bn name, its input y, partial buffer)] -- the BatchNorm layers whose
         backward consumes dx: the epilogue forms their reduction pass; returns {bn name: (partial, tiles)}."""
         wsp = self.wsp.get(name)
@@ -481,10 +484,10 @@ class ResNet18Encoder(FlatModule):
         reqs = [(y,) + tuple(ws["stats"][bn]) + (part,) for bn, y, part in bn_next]
         if wsp is not None:
             r = ops.conv2d_dgrad_split(dy, wsp[1], w.shape, x_shape, stride, pad, dx=dx, residual=residual, relu_src=relu_src,
-                                       stream=st, bn_reqs=reqs)
+                                       stream=st, bn_reqs=reqs, class_mask=class_mask, residual_mask=residual_mask)
         else:
             r = ops.conv2d_dgrad(dy, w, x_shape, stride, pad, ws["wt_ws"], dx=dx, residual=residual, relu_src=relu_src, stream=st,
-                                 bn_reqs=reqs)
+                                 bn_reqs=reqs, class_mask=class_mask, residual_mask=residual_mask)
         return {bn: (part, r[1]) for bn, _, part in bn_next} if bn_next else {}
 
     def _backward_trunk(self, ws, st) -> None:
@@ -525,9 +528,17 @@ class ResNet18Encoder(FlatModule):
                 dyd = DY[pre + ".downsample.0"]
                 self._bn_bwd(ws, st, pre + ".downsample.1", d, blk["yd"], dyd, have.pop(pre + ".downsample.1", None))
                 self._wgrad(ws, xin, dyd, pre + ".downsample.0", blk["stride"], 0)
-                self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx)
-                have = self._dgrad(ws, st, dyd, pre + ".downsample.0", xin.shape, blk["stride"], 0, dx, residual=dx, relu_src=mask,
-                                   bn_next=nxt)
+                if blk["stride"] == 2 and DS_DGRAD_FOLD:
+                    # the 1x1 / stride-2 downsample reaches the (even, even) pixels only: it writes that parity class (one launch),
+                    # conv1's four class launches then add onto it there, apply the block-input ReLU mask and form the BatchNorm
+                    # reductions of the block below -- instead of a second full read-modify-write pass over dx in four launches
+                    self._dgrad(ws, st, dyd, pre + ".downsample.0", xin.shape, 2, 0, dx, class_mask=0x1)
+                    have = self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, 2, 1, dx, residual=dx, relu_src=mask, bn_next=nxt,
+                                       residual_mask=0x1)
+                else:
+                    self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx)
+                    have = self._dgrad(ws, st, dyd, pre + ".downsample.0", xin.shape, blk["stride"], 0, dx, residual=dx, relu_src=mask,
+                                       bn_next=nxt)
             else:
                 have = self._dgrad(ws, st, dy1, pre + ".conv1", xin.shape, blk["stride"], 1, dx, residual=d, relu_src=mask,
                                    bn_next=nxt)

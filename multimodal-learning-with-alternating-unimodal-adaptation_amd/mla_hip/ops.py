@@ -159,9 +159,11 @@ def _bn_reqs(bn_reqs, x_shape):
 
 def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_shape, stride: int, pad: int, wt_ws: torch.Tensor,
                  dx: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                 relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None, bn_reqs=None):
+                 relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None, bn_reqs=None,
+                 class_mask: int = 0xF, residual_mask: int = 0xF):
     """Input gradient.  With bn_reqs (see _bn_reqs) the epilogue also forms the reduction pass of those BatchNorm
-    backwards and the call returns (dx, tiles) for bn_bwd_from_partial."""
+    backwards and the call returns (dx, tiles) for bn_bwd_from_partial.  class_mask / residual_mask: output parity classes
+    (bit py * stride + px) to compute / to add `residual` in (include/mla_hip.h: mla_conv2d_dgrad_classes)."""
     N, H, W, Cin = x_shape
     KH, KW, _, Cout = w_hwio.shape
     if dx is None:
@@ -171,9 +173,10 @@ def conv2d_dgrad(dy: torch.Tensor, w_hwio: torch.Tensor, x_shape, stride: int, p
     arr, nreq = _bn_reqs(bn_reqs, x_shape)
     tiles = ctypes.c_int(0)
     t0 = TIMER.begin() if TIMER is not None else None
-    check(_lib.load().mla_conv2d_dgrad_bn(_p(dy), _p(w_hwio), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                          _p(residual), _p(relu_src), _p(wt_ws), ctypes.addressof(arr) if nreq else None, nreq,
-                                          ctypes.addressof(tiles), stream or cur_stream()), "mla_conv2d_dgrad_bn")
+    check(_lib.load().mla_conv2d_dgrad_classes(_p(dy), _p(w_hwio), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                               _p(residual), _p(relu_src), _p(wt_ws), ctypes.addressof(arr) if nreq else None, nreq,
+                                               ctypes.addressof(tiles), class_mask, residual_mask, stream or cur_stream()),
+          "mla_conv2d_dgrad_classes")
     if t0 is not None:
         TIMER.end("conv_dgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
     return (dx, tiles.value) if nreq else dx
@@ -224,7 +227,8 @@ def conv2d_fwd_split(x: torch.Tensor, wsplit_t: torch.Tensor, w_shape, stride: i
 
 def conv2d_dgrad_split(dy: torch.Tensor, wsplit: torch.Tensor, w_shape, x_shape, stride: int, pad: int,
                        dx: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                       relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None, bn_reqs=None):
+                       relu_src: Optional[torch.Tensor] = None, stream: Optional[int] = None, bn_reqs=None,
+                       class_mask: int = 0xF, residual_mask: int = 0xF):
     """conv2d_dgrad on the split-bf16 MFMA path; `wsplit` = conv2d_wsplit(w, False).  bn_reqs as in conv2d_dgrad."""
     N, H, W, Cin = x_shape
     KH, KW, _, Cout = w_shape
@@ -233,10 +237,10 @@ def conv2d_dgrad_split(dy: torch.Tensor, wsplit: torch.Tensor, w_shape, x_shape,
     arr, nreq = _bn_reqs(bn_reqs, x_shape)
     tiles = ctypes.c_int(0)
     t0 = TIMER.begin() if TIMER is not None else None
-    check(_lib.load().mla_conv2d_dgrad_split_bn(_p(dy), _p(wsplit, torch.int16), _p(dx), N, H, W, Cin, Cout, KH, KW, stride,
-                                                pad, _p(residual), _p(relu_src), ctypes.addressof(arr) if nreq else None, nreq,
-                                                ctypes.addressof(tiles), stream or cur_stream()),
-          "mla_conv2d_dgrad_split_bn")
+    check(_lib.load().mla_conv2d_dgrad_split_classes(_p(dy), _p(wsplit, torch.int16), _p(dx), N, H, W, Cin, Cout, KH, KW, stride,
+                                                     pad, _p(residual), _p(relu_src), ctypes.addressof(arr) if nreq else None, nreq,
+                                                     ctypes.addressof(tiles), class_mask, residual_mask, stream or cur_stream()),
+          "mla_conv2d_dgrad_split_classes")
     if t0 is not None:
         TIMER.end("conv_dgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
     return (dx, tiles.value) if nreq else dx
