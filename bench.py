@@ -100,6 +100,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="disable the per-encoder stream pipeline (serialized kernels)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with the other conv arithmetic (N=1 only)")
+    ap.add_argument("--no-unfused", action="store_true", help="skip the extra serialized pass that times the un-fused BatchNorm reductions (profiling runs)")
     ap.add_argument("--math", choices=["f32", "split"], default=os.environ.get("MLA_CONV_MATH", "split"),
                     help="conv forward/dgrad arithmetic: f32 = exact fp32 MFMA; split = exact 3-way bf16 operand split, "
                          "6 bf16 MFMAs per fp32 product (fp32-equivalent accuracy, see DESIGN.md)")
@@ -182,7 +183,7 @@ def main() -> None:
     # (every BatchNorm backward then runs its own reduce kernel; encoder.FUSE_BN_REDUCE is read at call time).
     from mla_hip import encoder as _enc
     timer_unfused = ops.KernelTimer()
-    if world == 1:
+    if world == 1 and not a.no_unfused:
         _enc.FUSE_BN_REDUCE = False
         trainer.train_step(spec, image, label, 0, len_dl)
         sync()
@@ -251,12 +252,14 @@ def main() -> None:
         achieved = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         split = a.math == "split"
         peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        kname = ("igemm_split_kernel (conv forward + input gradient, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product; "
-                 "peak = bf16 MFMA rate / 6)") if split else "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)"
+        kname = ("igemm_split_kernel + patch_split_kernel (conv forward + input gradient of the 64..512-channel layers, 6 x "
+                 "v_mfma_f32_32x32x16_bf16 per fp32 product; peak = bf16 MFMA rate / 6)") if split else \
+                "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)"
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_igemm_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01f_igemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_igemm_traffic.json")
+        for older in ("r02_igemm_traffic.json", "r01f_igemm_traffic.json"):
+            if not os.path.exists(tpath):
+                tpath = os.path.join(ROOT, "profiles", older)
         if os.path.exists(tpath):     # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE) of this same command, per conv call
             tj = json.load(open(tpath))
             traffic = round(tj["split" if split else "f32"]["hbm_bytes_per_call"])

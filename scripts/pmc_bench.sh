@@ -8,7 +8,7 @@ for MATH in split f32; do
   for CNT in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     tag=${MATH}_$(echo $CNT | cut -d' ' -f1)
     d=gpurun_out/pmc_$R/$tag; mkdir -p $d
-    timeout -k 10 280 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $d -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-overlap --math $MATH > $d/stdout.json 2> $d/stderr.log || { tail -5 $d/stderr.log; exit 1; }
+    timeout -k 10 280 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $d -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-unfused --no-overlap --math $MATH > $d/stdout.json 2> $d/stderr.log || { tail -5 $d/stderr.log; exit 1; }
     echo "$tag done"
   done
 done

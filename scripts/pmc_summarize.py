@@ -8,7 +8,7 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(ROOT, "gpurun_out", f"pmc_{R}")
 STEPS = 3          # 1 warm-up + 2 timed + (bench.py's serialized roofline pass: 1 + 2) = 6 steps in the process
-CALLS_PER_STEP = 78
+CALLS_PER_STEP = 76        # conv forward + input-gradient calls of the 64..512-channel layers (the stem runs on its own kernels since round 3)
 
 
 def counters(tag):
@@ -26,18 +26,21 @@ def short(name):
 
 
 traffic, util = {}, {}
-for math, kname in (("f32", "igemm_kernel"), ("split", "igemm_split_kernel")):
+for math, kname in (("f32", ("igemm_kernel",)), ("split", ("igemm_split_kernel", "patch_split_kernel"))):
     f = counters(f"{math}_FETCH_SIZE")
     w = counters(f"{math}_WRITE_SIZE")
     if not f or not w:
         continue
-    fs = [d["FETCH_SIZE"] for k, v in f.items() if short(k).startswith(kname + "<") and "true>" not in k for d in v]
-    ws = [d["WRITE_SIZE"] for k, v in w.items() if short(k).startswith(kname + "<") and "true>" not in k for d in v]
+    def mine(k):
+        sk = short(k).replace("(anonymous namespace)::", "")
+        return any(sk.startswith(n + "<") for n in kname) and "true>" not in k
+    fs = [d["FETCH_SIZE"] for k, v in f.items() if mine(k) for d in v]
+    ws = [d["WRITE_SIZE"] for k, v in w.items() if mine(k) for d in v]
     n = len(fs)
     steps_in_process = 6
     per_launch = (2 * sum(fs) / n + sum(ws) / len(ws)) * 1024
     per_step = per_launch * n / steps_in_process
-    traffic[math] = {"kernel": kname, "launches_profiled": n, "fetch_size_kb_per_launch": sum(fs) / n,
+    traffic[math] = {"kernel": " + ".join(kname), "launches_profiled": n, "fetch_size_kb_per_launch": sum(fs) / n,
                      "write_size_kb_per_launch": sum(ws) / len(ws), "hbm_bytes_per_launch": per_launch,
                      "kernel_launches_per_step": n / steps_in_process, "conv_calls_per_step": CALLS_PER_STEP,
                      "hbm_bytes_per_step": per_step, "hbm_bytes_per_call": per_step / CALLS_PER_STEP}
@@ -55,8 +58,8 @@ traffic["method"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separat
                      "--no-alt --no-overlap --math {f32,split}`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per "
                      "128-B request, MI355X_MICROARCH.md HBM section), averaged over all launches of the kernel")
 traffic["note"] = ("a conv forward / input-gradient CALL (what bench.py's roofline counts: 40 + 38 per step) is one kernel launch, except a "
-                   "stride-2 input gradient, which is one launch per output parity class; hbm_bytes_per_call = bytes per step / 78; the stem "
-                   "(scalar-gather igemm_kernel<..., true>) is excluded")
+                   "stride-2 input gradient, which is one launch per output parity class; hbm_bytes_per_call = bytes per step / 76; the stem "
+                   "kernels are excluded")
 util["method"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over the same command; "
                   "mfma_busy_frac = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE) / 8 XCDs x 256 CUs x 4 SIMDs), the same formula as round 1")
 json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{R}_igemm_traffic.json"), "w"), indent=1)

@@ -296,6 +296,30 @@ def test_rccl_path_single_rank_matches_local():
         os.makedirs(d, exist_ok=True)
         json.dump(rep, open(os.path.join(d, "head_exchange_rccl_1rank.json"), "w"), indent=1)
         assert us_head < 5000
+        # The PROTOCOL path (mla_hip.DataParallel: packed dW|db all-reduce inside HeadLinear.backward, asynchronous bucketed
+        # encoder-gradient all-reduce awaited by FusedSGD.step(), feature-mean all-reduce in GSPlugin) on the same forced
+        # single-rank RCCL group: the reference's loop (main.py:431-476) must give bit-identical parameters with and without it.
+        import mla_hip
+        from test_protocol_gpu import Args as PArgs, inputs as p_inputs, reference_loop_body
+
+        def protocol_run(comm):
+            model, _tr, _ = build(seed, "as_intended", False)
+            del _tr
+            model = mla_hip.DataParallel(model, device_ids=[0], comm=comm)
+            opt = mla_hip.FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+            gs, crit = mla_hip.GSPlugin(), mla_hip.CrossEntropyLoss()
+            model.train()
+            for step in range(2):
+                spec, image, label = p_inputs(seed, step, B, (128, 64), 2, (64, 64))
+                opt.zero_grad()
+                reference_loop_body(PArgs(), model, opt, gs, crit, spec, image, label, step, 10, 0.55, {}, False)
+            torch.cuda.synchronize()
+            m = model.module
+            return m.audio_net.flat.clone(), m.visual_net.flat.clone(), m.fusion_module.fc_out.flat.clone(), gs.Pl.clone()
+        got_d = protocol_run(Comm(force=True, bucket_bytes=8 << 20))
+        got_l = protocol_run(Comm())
+        for a, b, nm in zip(got_d, got_l, ("audio", "visual", "head", "Pl")):
+            assert torch.equal(a, b), f"protocol path over a 1-rank RCCL group changed {nm}"
     finally:
         dist.destroy_process_group()
 
