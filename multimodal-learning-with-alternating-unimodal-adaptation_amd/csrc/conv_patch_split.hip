@@ -17,6 +17,7 @@
 // Geometry, tap tables (forward: (kh - 1, kw - 1); input gradient: (1 - kh, 1 - kw) on the transposed weights) and the whole
 // epilogue (BatchNorm statistics, residual, ReLU mask, fused BatchNorm-backward reductions) are those of igemm_split_kernel.
 #include "split_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,6 +26,14 @@ constexpr int PT_MAXPX = 480;                 // patch pixels incl. the zero pix
 constexpr int PT_PPL = PT_MAXPX * 16;         // dwords per patch plane
 constexpr int PT_NPRE = (PT_MAXPX * 8 + 511) / 512;   // float4 patch slots per thread (32 channels = 8 float4 per pixel): 8
 constexpr int PT_ZP = PT_MAXPX - 1;
+
+template <int AUX>
+__device__ __forceinline__ float buf_load1i(rsrc_t r, unsigned voff, int imm) {       // imm: folded into the instruction's 12-bit offset
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(voff + (unsigned)imm), 0, AUX));
+}
+__device__ __forceinline__ void buf_store1i(rsrc_t r, float v, unsigned voff, int imm) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)(voff + (unsigned)imm), 0, 0);
+}
 
 template <int BN>
 __global__ __launch_bounds__(512, 2) void patch_split_kernel(const float* __restrict__ X, const void* __restrict__ Wsp, float* Y,
@@ -211,6 +220,274 @@ __global__ __launch_bounds__(512, 2) void patch_split_kernel(const float* __rest
   igemm_epilogue<PT_BM, BN, WM, WN>(acc, rowinfo, reinterpret_cast<float*>(P), Y, R, MASK, part, nullptr, nullptr, g, tm, tn);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent variant for the 64 -> 64 channel layers (layer1: 16 of the 76 forward / input-gradient calls of a step, and the
+// most memory-heavy ones: 38.7 GFLOP against 270 MB (forward) ... 670 MB (input gradient with residual, ReLU mask and the
+// BatchNorm-backward reduction reading its input) per call).  With one 145-KB workgroup per CU nothing overlaps a tile's
+// epilogue: the round-3 kernel trace shows patch_split_kernel<64> at 266 us per call against 212 us with the epilogue
+// compiled out.  Here a workgroup walks tiles; the whole weight / patch stage stream runs on across tile boundaries (the
+// next tile's first patch is prefetched during this tile's last chunk), and the EPILOGUE of tile t -- its loads of residual /
+// mask / BatchNorm input, the arithmetic, the stores and the column statistics -- is cut into eight 4-row pieces that ride in
+// the MFMA stages of tile t + 1: a piece's operands are loaded in one stage and consumed in the next.  Statistics are kept per
+// lane for the whole launch and reduced once at the end: one partial row per workgroup (no barrier inside the epilogue).
+// Cin = Cout = 64 only: 2 chunks x 5 two-tap stages = 10 unrolled stages per tile.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool HAS_R, bool HAS_MASK, int NREQ, bool STATS>
+__global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__ X, const void* __restrict__ Wsp, float* Y,
+                                                           const float* R, const float* MASK, double* __restrict__ part,
+                                                           const IGemmGeom g, int ntiles) {
+  constexpr int BN = 64, WN = 2, MI = 2, TPS = 2, SPC = 5, NC = 2, NSTG = NC * SPC;
+  constexpr int BSLOT = 3 * 128 * 16;
+  __shared__ __attribute__((aligned(16))) unsigned P[3 * PT_PPL];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[2 * BSLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int i = lane & 31, h = lane >> 5;
+  const int gH = g.H, gW = g.W;
+  const int prow = gW + 2;
+  const int col = wn * 32 + i;                                  // this lane's output column
+  const unsigned plane_bytes = g.w_bytes / 2;
+  const unsigned t_bytes = (unsigned)g.M * 64u * 4u;           // every (M, 64) fp32 tensor of this launch
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), wr = make_rsrc(Wsp, 3 * plane_bytes), yr = make_rsrc(Y, t_bytes);
+  const rsrc_t rr = make_rsrc(HAS_R ? R : Y, t_bytes), mr = make_rsrc(HAS_MASK ? MASK : Y, t_bytes);
+  const rsrc_t b0r = make_rsrc(NREQ > 0 ? g.bn_x[0] : Y, t_bytes), b1r = make_rsrc(NREQ > 1 ? g.bn_x[1] : Y, t_bytes);
+
+  if (tid < 48) P[(tid >> 4) * PT_PPL + PT_ZP * 16 + (tid & 15)] = 0u;         // the zero pixel of the three planes
+
+  // ---- patch staging of (tile, chunk)
+  f32x4 pre[PT_NPRE];
+  const unsigned prow_inv = (65536u + (unsigned)prow - 1u) / (unsigned)prow;      // pp / prow == (pp * prow_inv) >> 16 for pp < 512, prow < 64
+  auto patch_load = [&](int tile, int c0) {
+    const int m0 = tile * PT_BM;
+    const int r0 = m0 / gW;
+    const int mlast = min(g.M, m0 + PT_BM) - 1;
+    const int npx = tile < ntiles ? (mlast / gW - r0 + 3) * prow : 0;
+    int zero = 0;
+    asm volatile("" : "+v"(zero));               // (keeps the eight slot addresses from being hoisted out of the tile loop: 30 VGPRs)
+#pragma unroll
+    for (int u = 0; u < PT_NPRE; ++u) {
+      const int s = tid + 512 * u + zero, pp = s >> 3, c4 = s & 7;
+      const int pr = (int)(((unsigned)pp * prow_inv) >> 16), pc = pp - pr * prow;
+      const int gr = r0 - 1 + pr, x = pc - 1;
+      const int ok = (int)(pp < npx) & (int)((unsigned)gr < (unsigned)(g.N * gH)) & (int)((unsigned)x < (unsigned)gW);
+      const unsigned off = ((unsigned)(gr * gW + x) * 64u + (unsigned)(c0 + 4 * c4)) * 4u;
+      pre[u] = buf_load4(xr, off | ((unsigned)ok - 1u), 0);
+    }
+  };
+  auto patch_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < PT_NPRE; ++u) {
+      const int s = tid + 512 * u, pp = s >> 3, c4 = s & 7;
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split_pair<true>(pre[u][0], pre[u][1], h0, m0_, l0);
+      split_pair<true>(pre[u][2], pre[u][3], h1, m1, l1);
+      // (the last slots would fall on the zero pixel: redirected onto pixel ZP - 1, which no tile reaches and which receives zeros)
+      const int ppc = pp < PT_ZP ? pp : PT_ZP - 1;
+      unsigned* dst = P + ppc * 16 + ((((c4 >> 1) ^ ((ppc >> 2) & 3)) << 2) + (c4 & 1) * 2);
+      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(dst + PT_PPL) = u32x2{m0_, m1};
+      *reinterpret_cast<u32x2*>(dst + 2 * PT_PPL) = u32x2{l0, l1};
+    }
+  };
+  u32x4 breg[3];
+  const int b_row = tid >> 2, b_tt = b_row / BN, b_n = b_row - b_tt * BN;
+  const unsigned b_base = (unsigned)(b_n * 64 * 2 + ((tid & 3) ^ ((b_row >> 2) & 3)) * 16);
+  auto b_load = [&](int t0, int c0) {
+    const int t = t0 + b_tt;
+    const int tp = g.tap[t < 9 ? t : 8];
+    unsigned off = b_base;
+    asm volatile("" : "+v"(off));
+    off = (off + (unsigned)(tap_wt(tp) * 64 * 64 * 2 + c0 * 2)) | ((unsigned)(t < 9) - 1u);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) breg[pl] = buf_load4u(wr, off, pl * plane_bytes);
+  };
+  auto b_store = [&](int slot) {
+    unsigned* dst = Bs + slot * BSLOT + tid * 4;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * 128 * 16) = breg[pl];
+  };
+  const int swz = (i >> 2) & 3;
+  const int b_rd = (wn * 32 + i) * 16;
+  struct Frags { bf16x8_t a[3][MI], b[3]; };
+  auto load_frags = [&](int slot, int tt, const int (&ppv)[MI], int kk, Frags& f) {
+    const unsigned* Br = Bs + slot * BSLOT + tt * BN * 16 + b_rd + (((kk * 2 + h) ^ swz) << 2);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const unsigned* Ar = P + pl * PT_PPL + ppv[mi] * 16 + (((kk * 2 + h) ^ ((ppv[mi] >> 2) & 3)) << 2);
+        f.a[pl][mi] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Ar));
+      }
+      f.b[pl] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4*>(Br + pl * 128 * 16));
+    }
+  };
+
+  // ---- epilogue state: the finished accumulators of the previous tile and the launch-long column statistics
+  f32x16 prev[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) prev[mi][e] = 0.f;
+  double csum = 0.0, csq = 0.0;                                 // STATS: forward BatchNorm statistics of this lane's column
+  float rb0 = 0.f, rb1[2] = {0.f, 0.f};                         // NREQ: sum v, sum v * xhat_q over every tile of this workgroup
+  float bmu[2] = {0.f, 0.f}, bis[2] = {0.f, 0.f};
+  if constexpr (NREQ > 0) { bmu[0] = g.bn_mean[0][col]; bis[0] = g.bn_invstd[0][col]; }
+  if constexpr (NREQ > 1) { bmu[1] = g.bn_mean[1][col]; bis[1] = g.bn_invstd[1][col]; }
+  struct Piece { float r[4], mk[4], bx[2][4]; };
+  // row (e4, piece p) of the previous tile, this lane's column: tile base + a constant; rows past M fall outside the buffer ranges
+  // (loads give 0, stores are dropped) and their accumulators are exact zeros (the zero pixel): no row masks anywhere.
+  unsigned prev_off = (unsigned)g.M * 256u;                     // no previous tile yet: every row is out of range
+  auto piece_load = [&](int p, Piece& pc) {
+    const unsigned off = prev_off + (unsigned)(((p >> 2) * 32 + 8 * (p & 3)) * 256);
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      if constexpr (HAS_R) pc.r[e4] = buf_load1i<0>(rr, off, e4 * 256);
+      if constexpr (HAS_MASK) pc.mk[e4] = buf_load1i<0>(mr, off, e4 * 256);
+      if constexpr (NREQ > 0) pc.bx[0][e4] = buf_load1i<0>(b0r, off, e4 * 256);
+      if constexpr (NREQ > 1) pc.bx[1][e4] = buf_load1i<0>(b1r, off, e4 * 256);
+    }
+  };
+  auto piece_finish = [&](int p, const Piece& pc) {
+    const int mi = p >> 2, eq = p & 3;
+    const unsigned off = prev_off + (unsigned)((mi * 32 + 8 * eq) * 256);
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      float v = prev[mi][4 * eq + e4];
+      if constexpr (HAS_R) v += pc.r[e4];
+      if constexpr (HAS_MASK) v = pc.mk[e4] > 0.f ? v : 0.f;
+      buf_store1i(yr, v, off, e4 * 256);
+      if constexpr (STATS) {                                      // fp64 as in igemm_epilogue (rows past M are exact zeros); rides in the MFMA shadow
+        const double vd = (double)v;
+        csum += vd;
+        csq = fma(vd, vd, csq);
+      }
+      if constexpr (NREQ > 0) {
+        rb0 += v;
+        rb1[0] = fmaf(v, (pc.bx[0][e4] - bmu[0]) * bis[0], rb1[0]);
+      }
+      if constexpr (NREQ > 1) rb1[1] = fmaf(v, (pc.bx[1][e4] - bmu[1]) * bis[1], rb1[1]);
+    }
+  };
+  // ---- stage stream
+  int tile = blockIdx.x;
+  patch_load(tile, 0);
+  b_load(0, 0);
+  __syncthreads();                               // the zero pixel is written
+  patch_store();
+  b_store(0);
+  __syncthreads();
+  Frags f0;
+  Piece pcA;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * PT_BM;
+    const int r0 = m0 / gW;
+    int pb[MI], pv[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {            // this lane's two output rows: patch pixel at tap (0, 0) and validity bits
+      const int m = m0 + wm * 64 + mi * 32 + i;
+      const int gr = m / gW, ox = m - gr * gW;
+      const int n = gr / gH, oy = gr - n * gH;
+      pb[mi] = (gr - r0 + 1) * prow + ox + 1;
+      pv[mi] = m < g.M ? (4 | (oy >= 1 ? 1 : 0) | (oy + 1 < gH ? 2 : 0)) : 0;
+    }
+    f32x16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NSTG; ++k) {
+      const int c = k / SPC, st = k - c * SPC, cur = k & 1;
+      {                                          // next stage's weights (the stage sequence repeats every tile)
+        const int k1 = (k + 1) % NSTG;
+        b_load((k1 % SPC) * TPS, (k1 / SPC) * 32);
+      }
+      if (k == 0) patch_load(tile, 32);                          // this tile's second chunk
+      if (k == SPC) patch_load(tile + (int)gridDim.x, 0);        // the next tile's first chunk (masked off past the last tile)
+      // previous tile's epilogue: piece k's operands are requested now, piece k - 1 (requested a stage ago) is finished
+      if (k >= 1 && k <= 8) piece_finish(k - 1, pcA);
+      if (k < 8) piece_load(k, pcA);
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) {
+        const int t = st * TPS + tt;
+        if (t < 9) {
+          const int tp = g.tap[t];
+          const int dy = tap_dy(tp), dx = tap_dx(tp);
+          const int toff = dy * prow + dx;
+          const int need = 4 | (dy < 0 ? 1 : 0) | (dy > 0 ? 2 : 0);
+          int ppv[MI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ppv[mi] = (pv[mi] & need) == need ? pb[mi] + toff : PT_ZP;
+          load_frags(cur, tt, ppv, 0, f0);
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.a[TERM_A[term]][mi], f0.b[TERM_B[term]], acc[mi], 0, 0, 0);
+          if (tt == 0) b_store(cur ^ 1);                          // that slot's readers passed the previous barrier
+          load_frags(cur, tt, ppv, 1, f0);
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.a[TERM_A[term]][mi], f0.b[TERM_B[term]], acc[mi], 0, 0, 0);
+        }
+      }
+      if (st == SPC - 1) {                       // chunk boundary: every wave is done with this patch
+        __syncthreads();
+        patch_store();
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) prev[mi] = acc[mi];
+    prev_off = ((unsigned)(m0 + wm * 64 + 4 * h) * 64u + (unsigned)col) * 4u;
+  }
+  // ---- the last tile's epilogue, then the launch-long statistics: reduce over the row halves (h) and the four row waves
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    piece_load(p, pcA);
+    piece_finish(p, pcA);
+  }
+  if constexpr (STATS || NREQ > 0) {
+    __syncthreads();
+    double* redd = reinterpret_cast<double*>(P);                // [wm 4][2][64] doubles / [wm 4][3][64] floats
+    float* redf = reinterpret_cast<float*>(P) + 4096;
+    if constexpr (STATS) {
+      csum += __shfl_xor(csum, 32, 64);
+      csq += __shfl_xor(csq, 32, 64);
+      if (h == 0) { redd[(wm * 2 + 0) * 64 + col] = csum; redd[(wm * 2 + 1) * 64 + col] = csq; }
+    }
+    if constexpr (NREQ > 0) {
+      rb0 += __shfl_xor(rb0, 32, 64);
+      rb1[0] += __shfl_xor(rb1[0], 32, 64);
+      rb1[1] += __shfl_xor(rb1[1], 32, 64);
+      if (h == 0) { redf[(wm * 3 + 0) * 64 + col] = rb0; redf[(wm * 3 + 1) * 64 + col] = rb1[0]; redf[(wm * 3 + 2) * 64 + col] = rb1[1]; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      if constexpr (STATS) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s += redd[(w * 2 + 0) * 64 + tid]; q += redd[(w * 2 + 1) * 64 + tid]; }
+        part[((size_t)blockIdx.x * 2 + 0) * 64 + tid] = s;
+        part[((size_t)blockIdx.x * 2 + 1) * 64 + tid] = q;
+      }
+      if constexpr (NREQ > 0) {
+        float s = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s += redf[(w * 3 + 0) * 64 + tid]; q0 += redf[(w * 3 + 1) * 64 + tid]; q1 += redf[(w * 3 + 2) * 64 + tid]; }
+        const size_t o = ((size_t)(g.bn_tile0 + blockIdx.x) * 2) * 64 + tid;
+        g.bn_part[0][o] = s;
+        g.bn_part[0][o + 64] = q0;
+        if constexpr (NREQ > 1) { g.bn_part[1][o] = s; g.bn_part[1][o + 64] = q1; }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // (not part of the C ABI: called by launch_split in conv_igemm_split.hip)
@@ -235,12 +512,45 @@ bool mla_patch_supported(const IGemmGeom& g, bool force) {
   return wgs * 4 >= rounds * 256 * 3;                                        // >= 75 % of the slots of its rounds are used
 }
 
+static int g_patch_persistent = -1;       // -1: $MLA_PATCH_PERSISTENT (default 1)
+static bool patch_persistent_on() {
+  if (g_patch_persistent < 0) {
+    const char* e = getenv("MLA_PATCH_PERSISTENT");
+    g_patch_persistent = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_patch_persistent != 0;
+}
+
 int mla_patch_launch(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part, const IGemmGeom& g,
                      int* bn_tiles, hipStream_t st) {
   const int BN = g.CO % 128 == 0 ? 128 : 64;
-  const int total = cdiv(g.M, PT_BM) * (g.CO / BN);
-  if (bn_tiles) *bn_tiles = cdiv(g.M, PT_BM);
-  if (total <= 0) return MLA_OK;
+  const int tiles = cdiv(g.M, PT_BM);
+  const int total = tiles * (g.CO / BN);
+  if (total <= 0) { if (bn_tiles) *bn_tiles = 0; return MLA_OK; }
+  const int nreq = g.bn_x[0] ? (g.bn_x[1] ? 2 : 1) : 0;
+  // layer1 (64 -> 64): the persistent kernel with the epilogue riding in the next tile's MFMA stages, for the operand
+  // combinations the training step uses (everything else: the one-tile-per-workgroup kernel below)
+  if (g.C == 64 && g.CO == 64 && patch_persistent_on() && (long)g.M * 64 * 4 < 0xFFFFFFF0L && tiles >= 2) {
+    const int grid = tiles < 256 ? tiles : 256;
+    double* pd = reinterpret_cast<double*>(part);
+    bool done = true;
+#define P64(R_, M_, N_, S_) patch64p_kernel<R_, M_, N_, S_><<<grid, 512, 0, st>>>(X, Wsp, Y, R, MASK, pd, g, tiles)
+    if (!R && !MASK && nreq == 0 && part) P64(false, false, 0, true);            // forward, training
+    else if (!R && !MASK && nreq == 0) P64(false, false, 0, false);              // forward, evaluation
+    else if (!R && MASK && nreq == 1 && !part) P64(false, true, 1, false);       // conv2 input gradient
+    else if (R && MASK && nreq == 1 && !part) P64(true, true, 1, false);         // conv1 input gradient, block below without downsample
+    else if (R && !MASK && nreq == 0 && !part) P64(true, false, 0, false);       // first block (after the max-pool)
+    else if (R && MASK && nreq == 0 && !part) P64(true, true, 0, false);         // (reductions not fused)
+    else if (!R && MASK && nreq == 0 && !part) P64(false, true, 0, false);
+    else done = false;
+#undef P64
+    if (done) {
+      MLA_CHECK_LAUNCH("patch64p_kernel");
+      if (bn_tiles) *bn_tiles = grid;
+      return MLA_OK;
+    }
+  }
+  if (bn_tiles) *bn_tiles = tiles;
   if (BN == 128) patch_split_kernel<128><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, g);
   else patch_split_kernel<64><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, g);
   MLA_CHECK_LAUNCH("patch_split_kernel");

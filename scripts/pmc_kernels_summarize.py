@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(base, "**", "*counter_collection.csv"), recursiv
 
 
 def short(n):
-    return n.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip()
+    return n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
 
 
 for k, c in sorted(per.items()):

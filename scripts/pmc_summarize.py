@@ -22,7 +22,7 @@ def counters(tag):
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
 
 
 traffic, util = {}, {}
@@ -32,7 +32,7 @@ for math, kname in (("f32", ("igemm_kernel",)), ("split", ("igemm_split_kernel",
     if not f or not w:
         continue
     def mine(k):
-        sk = short(k).replace("(anonymous namespace)::", "")
+        sk = short(k)
         return any(sk.startswith(n + "<") for n in kname) and "true>" not in k
     fs = [d["FETCH_SIZE"] for k, v in f.items() if mine(k) for d in v]
     ws = [d["WRITE_SIZE"] for k, v in w.items() if mine(k) for d in v]
@@ -42,8 +42,8 @@ for math, kname in (("f32", ("igemm_kernel",)), ("split", ("igemm_split_kernel",
     per_step = per_launch * n / steps_in_process
     traffic[math] = {"kernel": " + ".join(kname), "launches_profiled": n, "fetch_size_kb_per_launch": sum(fs) / n,
                      "write_size_kb_per_launch": sum(ws) / len(ws), "hbm_bytes_per_launch": per_launch,
-                     "kernel_launches_per_step": n / steps_in_process, "conv_calls_per_step": CALLS_PER_STEP,
-                     "hbm_bytes_per_step": per_step, "hbm_bytes_per_call": per_step / CALLS_PER_STEP}
+                     "kernel_launches_per_step": n / steps_in_process, "conv_calls_per_step": CALLS_PER_STEP + (2 if math == "f32" else 0),
+                     "hbm_bytes_per_step": per_step, "hbm_bytes_per_call": per_step / (CALLS_PER_STEP + (2 if math == "f32" else 0))}
     u = counters(f"{math}_SQ_VALU_MFMA_BUSY_CYCLES")
     rows = {}
     for k, v in u.items():

@@ -142,6 +142,9 @@ PATCH_CASES = [
     (1, 5, 3, 64, 128),       # smaller than one tile, Cin != Cout
     (3, 56, 56, 64, 64),      # visual layer1 rows: the widest patch (8 rows x 58 pixels)
     (40, 14, 14, 256, 256),   # many tiles: the grid exceeds the CU count
+    (25, 56, 56, 64, 64),     # 64 -> 64 persistent kernel: 307 tiles on 256 workgroups (two tiles for some: the epilogue of the first rides
+                              # in the MFMA stages of the second), ragged last tile
+    (40, 64, 32, 64, 64),     # ... 320 whole tiles, audio-like maps
 ]
 
 
@@ -168,7 +171,9 @@ def test_conv_patch_fwd_dgrad(ops, case):
     finally:
         ops.conv2d_patch(default)
     torch.cuda.synchronize()
-    assert tiles == (N * H * W + 255) // 256 and torch.equal(y, y2)
+    ntiles = (N * H * W + 255) // 256
+    # statistics rows: one per 256-pixel tile; the persistent 64 -> 64 kernel keeps them per workgroup (at most one per CU)
+    assert tiles == (min(ntiles, 256) if (Cin == 64 and Cout == 64 and ntiles >= 2) else ntiles) and torch.equal(y, y2)
     y_ref = nchw(y_old.cpu()) if big else O.conv2d_fwd(x, w, 1, 1)
     if not big:
         assert_close(nchw(y_old.cpu()), y_ref, atol=0, rtol=2e-5, name="per-tap fwd")
@@ -196,6 +201,33 @@ def test_conv_patch_fwd_dgrad(ops, case):
         dx_ref = (O.conv2d_dgrad(dy, w, x.shape, 1, 1) + res) * (msk > 0)
         assert_close(nchw(dx_old.cpu()), dx_ref, atol=0, rtol=2e-5, name="per-tap dgrad")
     assert_close(nchw(dx.cpu()), dx_ref, atol=0, rtol=2e-5, name="patch dgrad")
+    # ... and with the reduction pass of the BatchNorm backward that consumes dx fused into the epilogue (with / without residual)
+    M = N * H * W
+    z = nhwc(O.portable_normal(seed, (N, Cin, H, W), stream=6, mean=0.3, std=1.5)).cuda()
+    zpart = torch.empty(ops.bn_stats_partial_elems(M, Cin), device="cuda")
+    zt = ops.bn_stats_partial(z.view(M, Cin), M, Cin, zpart)
+    mean, invstd = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    ops.bn_finalize(zpart, zt, M, Cin, mean, invstd, None, None)
+    gamma = O.portable_normal(seed, (Cin,), stream=9, mean=1.0, std=0.2).cuda()
+    for with_res in (True, False):
+        got = {}
+        try:
+            for mode in (2, 0):
+                ops.conv2d_patch(mode)
+                rpart = torch.full((ops.conv2d_dgrad_bn_partial_elems(N, H, W, Cin),), float("nan"), device="cuda")
+                dxr, rtiles = ops.conv2d_dgrad_split(dyd, wS, wd.shape, xd.shape, 1, 1, residual=resd if with_res else None, relu_src=mskd,
+                                                     bn_reqs=[(z, mean, invstd, rpart)])
+                o, dg, db = torch.empty_like(dxr), torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+                ops.bn_bwd_from_partial(dxr.view(M, Cin), z.view(M, Cin), mean, invstd, gamma, o.view(M, Cin), dg, db, rpart, rtiles, M, Cin)
+                torch.cuda.synchronize()
+                got[mode] = (dxr, dg, db, o)
+        finally:
+            ops.conv2d_patch(default)
+        if with_res:
+            assert torch.equal(got[2][0], dx), "the fused reductions must not change dx"
+        assert_close(got[2][1], got[0][1], atol=2e-6 * got[0][1].abs().max().item(), name=f"patch fused dgamma (residual={with_res})")
+        assert_close(got[2][2], got[0][2], atol=2e-6 * got[0][2].abs().max().item(), name=f"patch fused dbeta (residual={with_res})")
+        assert_close(got[2][3], got[0][3], atol=2e-6 * got[0][3].abs().max().item(), rtol=2e-5, name=f"patch fused BN dx (residual={with_res})")
 
 
 STEM_CASES = [
