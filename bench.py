@@ -252,7 +252,7 @@ def main() -> None:
         achieved = ig["work"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         split = a.math == "split"
         peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        kname = ("igemm_split_kernel + patch_split_kernel (conv forward + input gradient of the 64..512-channel layers, 6 x "
+        kname = ("igemm_split_kernel + patch_split_kernel + patch64p_kernel (conv forward + input gradient of the 64..512-channel layers, 6 x "
                  "v_mfma_f32_32x32x16_bf16 per fp32 product; peak = bf16 MFMA rate / 6)") if split else \
                 "igemm_kernel (conv forward + input gradient, v_mfma_f32_32x32x2_f32)"
         traffic, traffic_src = None, None
