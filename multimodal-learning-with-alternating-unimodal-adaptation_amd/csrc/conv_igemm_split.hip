@@ -695,9 +695,10 @@ static void wgrad_split_plan(long M, int Cin, int Cout, int T, int* span, int* s
 }
 
 // wgrad_tr_split.hip: persistent all-taps kernel for the 64 -> 64 channel 3x3 / 1 / 1 convolutions (layer1)
-bool mla_wgrad_tr_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
-size_t mla_wgrad_tr_ws_bytes();
-int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st);
+bool mla_wgrad_tr_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+size_t mla_wgrad_tr_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                        hipStream_t st);
 static int g_wgrad_tr = 1;
 extern "C" int mla_conv2d_wgrad_tr(int on) {          // measurement hook: 0 = the per-tap kernel everywhere, 1 = default; other: query
   if (on == 0 || on == 1) g_wgrad_tr = on;
@@ -709,7 +710,8 @@ extern "C" size_t mla_conv2d_wgrad_split_ws_bytes(int N, int H, int W, int Cin, 
   int span, splits;
   wgrad_split_plan(M, Cin, Cout, KH * KW, &span, &splits);
   size_t b = (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
-  if (mla_wgrad_tr_supported(Cin, Cout, KH, KW, stride, pad) && mla_wgrad_tr_ws_bytes() > b) b = mla_wgrad_tr_ws_bytes();
+  if (mla_wgrad_tr_supported(W, Cin, Cout, KH, KW, stride, pad) && mla_wgrad_tr_ws_bytes(N, H, W, Cin, Cout) > b)
+    b = mla_wgrad_tr_ws_bytes(N, H, W, Cin, Cout);
   return b;
 }
 
@@ -721,7 +723,8 @@ extern "C" int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw
   MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_wgrad_split: Cin=%d must be a multiple of 64 (the stem runs on mla_conv2d_wgrad)", Cin);
   MLA_REQUIRE(x && dy && dw && ws, "mla_conv2d_wgrad_split: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (g_wgrad_tr && mla_wgrad_tr_supported(Cin, Cout, KH, KW, stride, pad)) return mla_wgrad_tr_launch(x, dy, dw, N, H, W, ws, ws_bytes, st);
+  if (g_wgrad_tr && mla_wgrad_tr_supported(W, Cin, Cout, KH, KW, stride, pad))
+    return mla_wgrad_tr_launch(x, dy, dw, N, H, W, Cin, Cout, ws, ws_bytes, st);
   IGemmGeom g;
   make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
   g.y_bytes = (unsigned)((size_t)g.M * Cout * 4);

@@ -197,6 +197,197 @@ __global__ __launch_bounds__(512, 2) void wgrad_tr_split_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same all-taps scheme for the 128 / 256 / 512-channel 3x3 / stride 1 / pad 1 convolutions (layer2..layer4: 18 launches
+// per step on wgrad_split_kernel<128, 128> at 165-180 TFLOP/s, where every (tap, channel tile) re-gathers and re-splits both
+// operands).  Their maps are 28 / 14 / 7 pixels wide (audio: 16 / 8 / 4): 8 x 8 spatial tiles would waste up to half of the MFMA
+// work on them, so a tile here is 64 consecutive FLAT pixels of the (N, H, W) tensor and the input patch is the flat range
+// [p0 - W - 1, p0 + 64 + W + 1): a tap is still one row offset (dy W + dx), and a tile pixel whose neighbour falls off its image
+// (mask bit per pixel and tap, written to LDS by the staging pass) supplies the address of a zero row to the transposing read
+// instead.  A workgroup owns one (64 input channels) x (64 output channels) block pair and every `splits`-th tile; its slab is a
+// 64 x 64 window of a full-size [9][Cin][Cout] slab per split, so the ordered reduce of conv_igemm.hip applies unchanged.
+// All block pairs of one split are neighbours in the XCD-remapped order: the tiles they share come out of one L2.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WF_NPMAX = 122;                            // patch pixels 64 + 2 W + 2 for W <= 28
+constexpr int WF_ZR = WF_NPMAX;                          // the zero row behind every half plane of x
+constexpr int WF_XPL = 2 * (WF_NPMAX + 1) * 16;          // dwords per x plane: [2 halves][123 rows][16 dwords]
+constexpr int WF_YPL = 2 * 64 * 16;
+constexpr int WF_VT = 3 * WF_XPL + 3 * WF_YPL;           // validity table of the buffer's tile: 64 dwords
+constexpr int WF_BUF = WF_VT + 64;                       // 18016 dwords = 70.4 KB
+constexpr int WF_XU = 4, WF_YU = 2, WF_NLD = WF_XU + WF_YU;
+
+struct WfGeom {
+  int M, H, W, Cin, Cout, ntiles, splits, pairs, pairs_j;
+  unsigned x_bytes, y_bytes;
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad_flat_tr_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                                float* __restrict__ slabs, const WfGeom g) {
+  __shared__ __attribute__((aligned(16))) unsigned S[(2 * WF_BUF + 64 > WT_RACC ? 2 * WF_BUF + 64 : WT_RACC)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), yr = make_rsrc(dY, g.y_bytes);
+  const int lw = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int split = lw / g.pairs, pair = lw - split * g.pairs;
+  const int ci0 = (pair / g.pairs_j) * 64, co0 = (pair % g.pairs_j) * 64;
+  const int gW = g.W, NP = 64 + 2 * gW + 2;
+
+  f32x4 pre[WF_NLD];
+  auto stage_load = [&](int t, int vbuf) {         // vbuf: the LDS buffer this tile will be staged into (its validity table is written here)
+    const int p0 = t * 64;
+#pragma unroll
+    for (int u = 0; u < WF_NLD; ++u) {
+      const bool isx = u < WF_XU;
+      const int sl = tid + 512 * (isx ? u : u - WF_XU);
+      const int px = sl >> 4, c4 = sl & 15;
+      const int pix = isx ? p0 - gW - 1 + px : p0 + px;
+      const int ok = (int)(px < (isx ? NP : 64)) & (int)((unsigned)pix < (unsigned)g.M);
+      const unsigned off = isx ? ((unsigned)pix * (unsigned)g.Cin + (unsigned)(ci0 + c4 * 4)) * 4u
+                               : ((unsigned)pix * (unsigned)g.Cout + (unsigned)(co0 + c4 * 4)) * 4u;
+      pre[u] = buf_load4(isx ? xr : yr, wt_off_or_oob(ok, off), 0);
+    }
+    if (wave == 0) {                                  // tap-validity bits of tile pixel `lane`
+      const int pix = p0 + lane;
+      const int hw = g.H * gW;
+      const int rem = pix - (pix / hw) * hw;
+      const int y = rem / gW, x = rem - y * gW;
+      unsigned m = 0;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int yy = y + t9 / 3 - 1, xx = x + t9 % 3 - 1;
+        m |= (unsigned)((int)((unsigned)yy < (unsigned)g.H) & (int)((unsigned)xx < (unsigned)gW) & (int)(pix < g.M)) << t9;
+      }
+      S[vbuf * WF_BUF + WF_VT + lane] = m;            // no reader: that buffer's tile was finished before the last barrier
+    }
+  };
+  int pz = 0;                                       // an opaque 0, renewed per tile: keeps tile-invariant address arithmetic (LDS store
+                                                    // addresses of the six staging passes, the 36 patch rows of the fragment reads) from
+                                                    // being hoisted out of the tile loop into ~45 registers that then spill
+  auto stage_store = [&](int buf, int u) {
+    const bool isx = u < WF_XU;
+    const int sl = tid + pz + 512 * (isx ? u : u - WF_XU);
+    const int c4 = sl & 15, px = sl >> 4;
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair<true>(pre[u][0], pre[u][1], h0, m0, l0);
+    split_pair<true>(pre[u][2], pre[u][3], h1, m1, l1);
+    const int rows = isx ? WF_NPMAX + 1 : 64, pl = isx ? WF_XPL : WF_YPL;
+    const bool live = !isx || px < NP;                // patch slots past the last row (and the zero row itself) are not written
+    unsigned* dst = S + buf * WF_BUF + (isx ? 0 : 3 * WF_XPL) + ((c4 >> 3) * rows + px) * 16 + (c4 & 7) * 2;
+    if (!live) dst = S + 2 * WF_BUF + (tid & 31) * 2;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(live ? dst + pl : dst) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(live ? dst + 2 * pl : dst) = u32x2{l0, l1};
+  };
+
+  const int q = (lane & 15) >> 2, p = lane & 3, grp = (lane >> 4) & 1;
+  const int a_lane = wi * (WF_NPMAX + 1) * 16 + grp * 8 + p * 2;               // + row * 16
+  const int b_lane = 3 * WF_XPL + wj * 64 * 16 + grp * 8 + p * 2;             // + pixel * 16
+  int pixl[2];                                                                 // this lane's tile pixel (first of lo | hi = +4) in step s
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) pixl[s2] = (2 * (2 * sg + s2) + h) * 8 + q;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t9][e] = 0.f;
+
+  struct Fr { s16x4 lo[3], hi[3]; };
+  unsigned vm[2];
+  auto read_a = [&](const unsigned* Sc, int s2, int t9, Fr& f) {               // compile-time s2, t9
+    const int toff = (t9 / 3 - 1) * gW + (t9 % 3 - 1) + gW + 1;                // wave-uniform
+    const int rl = ((vm[s2] >> t9) & 1u) ? pixl[s2] + pz + toff : WF_ZR;
+    const int rh = ((vm[s2] >> (t9 + 9)) & 1u) ? pixl[s2] + pz + 4 + toff : WF_ZR;
+    const unsigned* al = Sc + a_lane + rl * 16;
+    const unsigned* ah = Sc + a_lane + rh * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      f.lo[pl] = lds_tr(al + pl * WF_XPL);
+      f.hi[pl] = lds_tr(ah + pl * WF_XPL);
+    }
+  };
+  auto read_b = [&](const unsigned* Sc, int s2, Fr& f) {
+    const unsigned* bp = Sc + b_lane + pixl[s2] * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      f.lo[pl] = lds_tr(bp + pl * WF_YPL);
+      f.hi[pl] = lds_tr(bp + pl * WF_YPL + 4 * 16);
+    }
+  };
+  auto frag = [&](const Fr& f, int pl) {
+    const u32x2 lo = __builtin_bit_cast(u32x2, f.lo[pl]), hi = __builtin_bit_cast(u32x2, f.hi[pl]);
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  for (int idx = tid; idx < 2 * WF_BUF + 64; idx += 512) S[idx] = 0u;
+  __syncthreads();
+  int cur = 0;
+  int t = split;
+  if (t < g.ntiles) stage_load(t, 0);
+  __syncthreads();
+  if (t < g.ntiles) {
+#pragma unroll
+    for (int u = 0; u < WF_NLD; ++u) stage_store(0, u);
+  }
+  __syncthreads();
+  constexpr int U = 2 * 9;
+  for (; t < g.ntiles; t += g.splits) {
+    const int tn = t + g.splits;
+    if (tn < g.ntiles) stage_load(tn, cur ^ 1);
+    const unsigned* Sc = S + cur * WF_BUF;
+    asm volatile("" : "+v"(pz));
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) vm[s2] = Sc[WF_VT + pixl[s2]] | (Sc[WF_VT + pixl[s2] + 4] << 9);   // tap bits of the lo | hi pixel
+    Fr a0, a1, b0;
+    read_b(Sc, 0, b0);
+    read_a(Sc, 0, 0, a0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s2 = u / 9, t9 = u - s2 * 9;
+      Fr& ac = (u & 1) ? a1 : a0;
+      Fr& an = (u & 1) ? a0 : a1;
+      Fr& bc = b0;
+      if (u == 9) read_b(Sc, 1, b0);                     // (one exposed LDS latency per tile: a second dy fragment set does not fit the 256 VGPRs)
+      if (u + 1 < U) read_a(Sc, (u + 1) / 9, (u + 1) % 9, an);
+      if (u >= U - WF_NLD) stage_store(cur ^ 1, u - (U - WF_NLD));
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+        acc[t9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ac, TERM_A[term]), frag(bc, TERM_B[term]), acc[t9], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- the two step groups' accumulators are summed in order through LDS; window (ci0, co0) of slab `split`
+  float* R = reinterpret_cast<float*>(S);
+  float* out = slabs + (size_t)split * 9 * g.Cin * g.Cout + (size_t)(ci0 + wi * 32 + 4 * h) * g.Cout + co0 + wj * 32 + i;
+  const int rl = ((wi * 32 + 4 * h) * 64) + wj * 32 + i;
+  if (sg == 0) {
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) R[rl + (t9 * 64 + (e & 3) + 8 * (e >> 2)) * 64] = acc[t9][e];
+  }
+  __syncthreads();
+  if (sg == 1) {
+    const unsigned tap_stride = (unsigned)g.Cin * (unsigned)g.Cout;
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        out[t9 * tap_stride + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)g.Cout] = R[rl + (t9 * 64 + (e & 3) + 8 * (e >> 2)) * 64] + acc[t9][e];
+  }
+}
+
 int wt_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -212,25 +403,56 @@ int wt_cus() {
 int mla_wgrad_reduce(const float* part, float* dw, size_t n4, int splits, hipStream_t st);   // conv_igemm.hip
 
 // (not part of the C ABI: called by mla_conv2d_wgrad_split in conv_igemm_split.hip)
-bool mla_wgrad_tr_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
-  return Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && pad == 1;
+static bool wf_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  return KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0 && 64 + 2 * W + 2 <= WF_NPMAX;
 }
-size_t mla_wgrad_tr_ws_bytes() { return (size_t)wt_cus() * WT_RACC * sizeof(float); }
+static void wf_plan(long M, int Cin, int Cout, int* pairs, int* splits) {
+  const long ntiles = (M + 63) / 64;
+  *pairs = (Cin / 64) * (Cout / 64);
+  long s = wt_cus() / *pairs;
+  if (s < 1) s = 1;
+  if (s > ntiles) s = ntiles;
+  *splits = (int)s;
+}
+bool mla_wgrad_tr_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  if (Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && pad == 1) return true;      // 8 x 8 spatial tiles, any map
+  return wf_supported(W, Cin, Cout, KH, KW, stride, pad);
+}
+size_t mla_wgrad_tr_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  if (Cin == 64 && Cout == 64) return (size_t)wt_cus() * WT_RACC * sizeof(float);
+  int pairs, splits;
+  wf_plan((long)N * H * W, Cin, Cout, &pairs, &splits);
+  return (size_t)splits * 9 * Cin * Cout * sizeof(float);
+}
 
-int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
-  WtGeom g;
-  g.N = N; g.H = H; g.W = W;
-  g.tilesY = cdiv(H, WT_TH); g.tilesX = cdiv(W, WT_TW);
-  g.ntiles = N * g.tilesY * g.tilesX;
-  MLA_REQUIRE((size_t)N * H * W * 64 * 4 < 0xFFFFFFF0UL, "mla_conv2d_wgrad_split: tensors must be < 4 GiB");
-  g.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
-  const int grid = g.ntiles < wt_cus() ? g.ntiles : wt_cus();
-  const size_t need = (size_t)grid * WT_RACC * sizeof(float);
+int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
+  const size_t need = mla_wgrad_tr_ws_bytes(N, H, W, Cin, Cout);
   if (ws_bytes < need) {
     mla_set_error("mla_conv2d_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
     return MLA_ERR_WORKSPACE;
   }
-  wgrad_tr_split_kernel<<<grid, 512, 0, st>>>(x, dy, (float*)ws, g);
-  MLA_CHECK_LAUNCH("wgrad_tr_split_kernel");
-  return mla_wgrad_reduce((const float*)ws, dw, (size_t)WT_RACC / 4, grid, st);
+  MLA_REQUIRE((size_t)N * H * W * Cin * 4 < 0xFFFFFFF0UL && (size_t)N * H * W * Cout * 4 < 0xFFFFFFF0UL,
+              "mla_conv2d_wgrad_split: tensors must be < 4 GiB");
+  if (Cin == 64 && Cout == 64) {
+    WtGeom g;
+    g.N = N; g.H = H; g.W = W;
+    g.tilesY = cdiv(H, WT_TH); g.tilesX = cdiv(W, WT_TW);
+    g.ntiles = N * g.tilesY * g.tilesX;
+    g.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
+    const int grid = g.ntiles < wt_cus() ? g.ntiles : wt_cus();
+    wgrad_tr_split_kernel<<<grid, 512, 0, st>>>(x, dy, (float*)ws, g);
+    MLA_CHECK_LAUNCH("wgrad_tr_split_kernel");
+    return mla_wgrad_reduce((const float*)ws, dw, (size_t)WT_RACC / 4, grid, st);
+  }
+  WfGeom g;
+  g.M = N * H * W; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
+  g.ntiles = cdiv(g.M, 64);
+  wf_plan(g.M, Cin, Cout, &g.pairs, &g.splits);
+  g.pairs_j = Cout / 64;
+  g.x_bytes = (unsigned)((size_t)g.M * Cin * 4);
+  g.y_bytes = (unsigned)((size_t)g.M * Cout * 4);
+  wgrad_flat_tr_kernel<<<g.pairs * g.splits, 512, 0, st>>>(x, dy, (float*)ws, g);
+  MLA_CHECK_LAUNCH("wgrad_flat_tr_kernel");
+  return mla_wgrad_reduce((const float*)ws, dw, (size_t)9 * Cin * Cout / 4, g.splits, st);
 }

@@ -101,20 +101,37 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
 SPLIT_CASES = [c for c in CONV_CASES if c[3] % 64 == 0] + [(2, 33, 17, 128, 128, 3, 1, 1)]   # M = 1122: ragged vs every tile
 
 
-@pytest.mark.parametrize("case", [(2, 20, 12), (3, 16, 8), (1, 8, 8), (5, 9, 11), (2, 56, 56), (64, 56, 24)], ids=lambda c: "x".join(map(str, c)))
+WGRAD_TR_CASES = [
+    # N, H, W, Cin, Cout.  64 -> 64: 8 x 8 spatial tiles (wgrad_tr_split_kernel)
+    (2, 20, 12, 64, 64), (3, 16, 8, 64, 64), (1, 8, 8, 64, 64), (5, 9, 11, 64, 64), (2, 56, 56, 64, 64), (64, 56, 24, 64, 64),
+    # wider layers on maps up to 28 pixels wide: 64-pixel flat tiles, one workgroup per 64 x 64 channel block pair and tile split
+    # (wgrad_flat_tr_kernel): tap validity by per-pixel mask bits, tiles that span image rows and whole images
+    (2, 28, 28, 128, 128),        # layer2 maps: 1568 pixels = 24.5 tiles, 4 block pairs
+    (3, 14, 14, 256, 256),        # 588 pixels: ragged last tile, a tile spans 4.6 image rows
+    (5, 7, 7, 512, 512),          # 7 x 7 maps: a tile holds 1.3 images; 64 block pairs x 4 splits
+    (2, 16, 8, 128, 256),         # Cin != Cout, audio-like
+    (1, 5, 3, 128, 128),          # smaller than one tile
+    (4, 32, 4, 512, 512),         # audio layer4: 4 pixels wide (every pixel touches a left / right border in some tap)
+    (3, 3, 1, 128, 128),          # one pixel wide
+    (64, 28, 28, 128, 128),       # 784 tiles: ~12 per workgroup
+    (48, 14, 14, 256, 256),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_TR_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_wgrad_all_taps_tr_kernel(ops, case):
-    """Weight gradient of the 64 -> 64 channel 3x3 / 1 / 1 convolutions (layer1) by the persistent all-taps kernel
-    (wgrad_tr_split.hip: transposing LDS reads, every tap from one staged patch) vs the oracle / the per-tap kernel at the
-    conv tolerance, ragged tiles included, bitwise reproducible."""
-    N, H, W = case
+    """Weight gradient of the 3x3 / 1 / 1 convolutions by the all-taps kernels (wgrad_tr_split.hip: transposing LDS reads, every
+    tap from one staged patch) vs the oracle / the per-tap kernel at the conv tolerance, ragged tiles included, bitwise
+    reproducible."""
+    N, H, W, Cin, Cout = case
     seed = sum(case) + 7
-    big = N * H * W > 20000
-    x = O.portable_normal(seed, (N, 64, H, W), stream=1)
-    dy = O.portable_normal(seed, (N, 64, H, W), stream=3)
+    big = N * H * W * max(Cin, Cout) > 1_300_000
+    x = O.portable_normal(seed, (N, Cin, H, W), stream=1)
+    dy = O.portable_normal(seed, (N, Cout, H, W), stream=3)
     xd, dyd = nhwc(x).cuda(), nhwc(dy).cuda()
-    ws = torch.empty(ops.conv2d_wgrad_split_ws_bytes(N, H, W, 64, 64, 3, 3, 1, 1) // 4 + 4, device="cuda")
+    ws = torch.empty(ops.conv2d_wgrad_split_ws_bytes(N, H, W, Cin, Cout, 3, 3, 1, 1) // 4 + 4, device="cuda")
     assert ops.conv2d_wgrad_tr() == 1
-    dw = torch.empty((3, 3, 64, 64), device="cuda")
+    dw = torch.empty((3, 3, Cin, Cout), device="cuda")
     ops.conv2d_wgrad_split(xd, dyd, dw, 1, 1, ws)
     dw_b = torch.empty_like(dw)
     ops.conv2d_wgrad_split(xd, dyd, dw_b, 1, 1, ws)
@@ -126,10 +143,12 @@ def test_wgrad_all_taps_tr_kernel(ops, case):
         ops.conv2d_wgrad_tr(1)
     torch.cuda.synchronize()
     assert torch.equal(dw, dw_b), "bitwise reproducible"
-    ref = oihw(dw_old.cpu()) if big else O.conv2d_wgrad(x, dy, (64, 64, 3, 3), 1, 1)
+    ref = oihw(dw_old.cpu()) if big else O.conv2d_wgrad(x, dy, (Cout, Cin, 3, 3), 1, 1)
     if not big:
         assert_close(oihw(dw_old.cpu()), ref, atol=0, rtol=2e-5, name="per-tap split wgrad")
     assert_close(oihw(dw.cpu()), ref, atol=0, rtol=2e-5, name="all-taps split wgrad")
+    if N * H * W > 64:      # (a single k-chunk can legitimately give the same bits)
+        assert not torch.equal(dw, dw_old), "the all-taps kernel did not run (same bits as the per-tap kernel)"
 
 
 PATCH_CASES = [
