@@ -770,10 +770,18 @@ extern "C" int mla_linear_dgrad_split(const float* dy, const void* wsplit, float
   return launch_split(dy, wsplit, dx, residual, gelu_src, nullptr, g, pick_scfg(g.M, K, 1), (hipStream_t)stream);
 }
 
+// wgrad_tr_split.hip: Linear weight gradient on transposing LDS reads (192 x 192 tiles; dense rows, K and N multiples of 192)
+bool mla_linear_wgrad_tr_supported(long M, int K, int N);
+size_t mla_linear_wgrad_tr_ws_bytes(long M, int K, int N);
+int mla_linear_wgrad_tr_launch(const float* x, const float* dy, float* dw_kn, float* dbias, int M, int K, int N, void* ws, size_t ws_bytes,
+                               hipStream_t st);
+
 extern "C" size_t mla_linear_wgrad_split_ws_bytes(int M, int K, int N) {
   int span, splits;
   wgrad_split_plan(M, K, N, 1, &span, &splits);
-  return (size_t)splits * K * N * sizeof(float) + (size_t)splits * N * sizeof(float);     // weight slabs + bias rows
+  size_t b = (size_t)splits * K * N * sizeof(float) + (size_t)splits * N * sizeof(float);     // weight slabs + bias rows
+  if (mla_linear_wgrad_tr_supported(M, K, N) && mla_linear_wgrad_tr_ws_bytes(M, K, N) > b) b = mla_linear_wgrad_tr_ws_bytes(M, K, N);
+  return b;
 }
 
 extern "C" int mla_linear_wgrad_split(const float* x, const float* dy, float* dw_kn, int groups, int rows, int x_group_rows,
@@ -790,6 +798,8 @@ extern "C" int mla_linear_wgrad_split_bias(const float* x, const float* dy, floa
   if (int rc = linear_geom("mla_linear_wgrad_split", g, groups, rows, x_group_rows, x_off, rows, 0, K, N)) return rc;
   g.y_bytes = (unsigned)((size_t)g.M * N * 4);
   hipStream_t st = (hipStream_t)stream;
+  if (g_wgrad_tr && (groups == 1 || (x_group_rows == rows && x_off == 0)) && x_off == 0 && mla_linear_wgrad_tr_supported(g.M, K, N))
+    return mla_linear_wgrad_tr_launch(x, dy, dw_kn, dbias, g.M, K, N, ws, ws_bytes, st);     // dense token rows
   int span, splits;
   wgrad_split_plan(g.M, K, N, 1, &span, &splits);
   const size_t need = (size_t)splits * K * N * sizeof(float) + (dbias ? (size_t)splits * N * sizeof(float) : 0);

@@ -388,6 +388,186 @@ __global__ __launch_bounds__(512, 1) void wgrad_flat_tr_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Linear weight gradient dW[k][n] = sum_m X[m][k] dY[m][n] (the transformer rows: 97 launches per M3AE step on
+// wgrad_split_kernel<128, 128>, 30 % of that step) with the same transposing-read scheme: no taps, so a wave spends its nine
+// 32 x 32 accumulators on a 96 x 96 block of dW instead -- 3 x-fragments and 3 dy-fragments feed 54 MFMAs per 16-row step (0.67
+// LDS reads per MFMA against 2 for one block).  Workgroup = 192 x 192 outputs: 2 step groups x (2 x 2) waves; a tile is 32 token
+// rows of both operands ([6 column groups][32 rows][32 columns] per bf16 plane, natural layout, 72 KB per buffer, two buffers);
+// grid = (K / 192) x (N / 192) x splits over the rows, one 192 x 192 window of a full-size slab per split, ordered reduce.
+// The bias gradient (column sums of dY) is accumulated from the staging registers of the workgroups with k-tile 0.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int LW_MS = 32;                                // token rows per tile
+constexpr int LW_PL = 6 * LW_MS * 16;                    // dwords per plane of one operand: 3072
+constexpr int LW_BUF = 6 * LW_PL;                        // x planes 0-2, dy planes 3-5: 18432 dwords = 72 KB
+constexpr int LW_NLD = 6;                                // float4 per thread and tile: 3 passes per operand (1536 slots each)
+
+struct LwGeom {
+  int M, K, N, tilesN, pairs, splits, mtiles;
+  unsigned x_bytes, y_bytes;
+};
+
+template <bool BIAS>
+__global__ __launch_bounds__(512, 1) void linear_wgrad_tr_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                                  float* __restrict__ slabs, float* __restrict__ bias_part,
+                                                                  const LwGeom g) {
+  __shared__ __attribute__((aligned(16))) unsigned S[(2 * LW_BUF + 64 > 192 * 192 ? 2 * LW_BUF + 64 : 192 * 192)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const rsrc_t xr = make_rsrc(X, g.x_bytes), yr = make_rsrc(dY, g.y_bytes);
+  const int lw = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int split = lw / g.pairs, pair = lw - split * g.pairs;
+  const int kt = pair / g.tilesN, nt = pair - kt * g.tilesN;
+  const int k0 = kt * 192, n0 = nt * 192;
+  const bool do_bias = BIAS && kt == 0;
+
+  f32x4 pre[LW_NLD];
+  f32x4 bacc[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) bacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int pz = 0;                                            // opaque 0 per tile (see wgrad_flat_tr_kernel)
+  auto stage_load = [&](int t) {
+    const int m0 = t * LW_MS;
+#pragma unroll
+    for (int u = 0; u < LW_NLD; ++u) {
+      const bool isx = u < 3;
+      const int sl = tid + pz + 512 * (isx ? u : u - 3);
+      const int row = sl / 48, c4 = sl - row * 48;
+      const int m = m0 + row;
+      const unsigned off = isx ? ((unsigned)m * (unsigned)g.K + (unsigned)(k0 + c4 * 4)) * 4u
+                               : ((unsigned)m * (unsigned)g.N + (unsigned)(n0 + c4 * 4)) * 4u;
+      pre[u] = buf_load4(isx ? xr : yr, wt_off_or_oob((int)(m < g.M), off), 0);
+    }
+  };
+  auto stage_store = [&](int buf, int u) {
+    const bool isx = u < 3;
+    const int sl = tid + pz + 512 * (isx ? u : u - 3);
+    const int row = sl / 48, c4 = sl - row * 48;
+    if (BIAS && !isx) bacc[u - 3] += pre[u];             // rows past M were loaded as zeros
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair<true>(pre[u][0], pre[u][1], h0, m0, l0);
+    split_pair<true>(pre[u][2], pre[u][3], h1, m1, l1);
+    unsigned* dst = S + buf * LW_BUF + (isx ? 0 : 3 * LW_PL) + ((c4 >> 3) * LW_MS + row) * 16 + (c4 & 7) * 2;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(dst + LW_PL) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(dst + 2 * LW_PL) = u32x2{l0, l1};
+  };
+
+  const int q = (lane & 15) >> 2, p = lane & 3, grp = (lane >> 4) & 1;
+  const int rd_lane = (16 * sg + 8 * h + q) * 16 + grp * 8 + p * 2;            // row of the lo read; hi = + 4 rows
+  const int a_lane = (3 * wi) * LW_MS * 16 + rd_lane;
+  const int b_lane = 3 * LW_PL + (3 * wj) * LW_MS * 16 + rd_lane;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t9][e] = 0.f;
+
+  struct Fr { s16x4 lo[3], hi[3]; };
+  auto read_fr = [&](const unsigned* base, int cgi, Fr& f) {                   // column group cgi of this wave's three
+    const unsigned* ap = base + cgi * LW_MS * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      f.lo[pl] = lds_tr(ap + pl * LW_PL);
+      f.hi[pl] = lds_tr(ap + pl * LW_PL + 4 * 16);
+    }
+  };
+  auto frag = [&](const Fr& f, int pl) {
+    const u32x2 lo = __builtin_bit_cast(u32x2, f.lo[pl]), hi = __builtin_bit_cast(u32x2, f.hi[pl]);
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  int cur = 0;
+  int t = split;
+  if (t < g.mtiles) stage_load(t);
+  if (t < g.mtiles) {
+#pragma unroll
+    for (int u = 0; u < LW_NLD; ++u) stage_store(0, u);
+  }
+  __syncthreads();
+  for (; t < g.mtiles; t += g.splits) {
+    const int tn = t + g.splits;
+    asm volatile("" : "+v"(pz));
+    if (tn < g.mtiles) {
+      stage_load(tn);                                    // in flight while this tile computes
+    } else if (BIAS) {                                   // no next tile: the staging passes below still run (their output is never read),
+#pragma unroll
+      for (int u = 3; u < LW_NLD; ++u) pre[u] = f32x4{0.f, 0.f, 0.f, 0.f};     // but must not count the last tile's dy twice
+    }
+    const unsigned* Sc = S + cur * LW_BUF;
+    Fr a0, a1, b[3];
+    read_fr(Sc + b_lane, 0, b[0]);
+    read_fr(Sc + a_lane, 0, a0);
+    read_fr(Sc + b_lane, 1, b[1]);
+    read_fr(Sc + b_lane, 2, b[2]);
+#pragma unroll
+    for (int ai = 0; ai < 3; ++ai) {
+      // x fragments: two sets in turn (the next one is read while this one multiplies); the bias variant has 12 registers less (its
+      // column sums) and keeps one set, re-read after the MFMAs that use it were issued
+      Fr& ac = BIAS ? a0 : ((ai & 1) ? a1 : a0);
+      Fr& an = BIAS ? a0 : ((ai & 1) ? a0 : a1);
+      if (!BIAS && ai + 1 < 3) read_fr(Sc + a_lane, ai + 1, an);
+      stage_store(cur ^ 1, 2 * ai);                      // unconditional (stale registers without a next tile: never read)
+      stage_store(cur ^ 1, 2 * ai + 1);
+#pragma unroll
+      for (int bj = 0; bj < 3; ++bj)
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+          acc[ai * 3 + bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ac, TERM_A[term]), frag(b[bj], TERM_B[term]), acc[ai * 3 + bj], 0, 0, 0);
+      if (BIAS && ai + 1 < 3) read_fr(Sc + a_lane, ai + 1, an);
+      if (!BIAS) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);           // the next x fragment's reads first
+#pragma unroll
+      for (int m = 0; m < 18; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        if (m % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- the two step groups' accumulators are summed in order through LDS; window (k0, n0) of slab `split`
+  float* R = reinterpret_cast<float*>(S);
+  const int rl = ((wi * 96 + 4 * h) * 192) + wj * 96 + i;
+  if (sg == 0) {
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) R[rl + ((t9 / 3) * 32 + (e & 3) + 8 * (e >> 2)) * 192 + (t9 % 3) * 32] = acc[t9][e];
+  }
+  __syncthreads();
+  if (sg == 1) {
+    float* out = slabs + (size_t)split * g.K * g.N + (size_t)(k0 + wi * 96 + 4 * h) * g.N + n0 + wj * 96 + i;
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (t9 / 3) * 32 + (e & 3) + 8 * (e >> 2), c = (t9 % 3) * 32;
+        out[(unsigned)r * (unsigned)g.N + c] = R[rl + r * 192 + c] + acc[t9][e];
+      }
+  }
+  if (BIAS) {
+    __syncthreads();
+    if (do_bias) {                                       // (uniform per workgroup) per-thread sums -> [32 row slots][192] -> column sums in row order
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int sl = tid + 512 * u, row = sl / 48, c4 = sl - row * 48;
+        *reinterpret_cast<f32x4*>(R + row * 192 + c4 * 4) = bacc[u];
+      }
+    }
+    __syncthreads();
+    if (do_bias && tid < 192) {
+      float sb = 0.f;
+      for (int r = 0; r < LW_MS; ++r) sb += R[r * 192 + tid];
+      bias_part[(size_t)split * g.N + n0 + tid] = sb;
+    }
+  }
+}
+
 int wt_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -456,3 +636,43 @@ int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H
   MLA_CHECK_LAUNCH("wgrad_flat_tr_kernel");
   return mla_wgrad_reduce((const float*)ws, dw, (size_t)9 * Cin * Cout / 4, g.splits, st);
 }
+
+// Linear weight gradient (not part of the C ABI: called by mla_linear_wgrad_split_bias in conv_igemm_split.hip).  Dense rows only.
+static void lw_plan(long M, int K, int N, int* pairs, int* splits) {
+  *pairs = (K / 192) * (N / 192);
+  const long mtiles = (M + LW_MS - 1) / LW_MS;
+  long s = wt_cus() / *pairs;
+  if (s < 1) s = 1;
+  if (s > mtiles) s = mtiles;
+  *splits = (int)s;
+}
+bool mla_linear_wgrad_tr_supported(long M, int K, int N) { return K % 192 == 0 && N % 192 == 0 && M >= 4 * LW_MS; }
+size_t mla_linear_wgrad_tr_ws_bytes(long M, int K, int N) {
+  int pairs, splits;
+  lw_plan(M, K, N, &pairs, &splits);
+  return (size_t)splits * K * N * sizeof(float) + (size_t)splits * N * sizeof(float);
+}
+int mla_linear_wgrad_tr_launch(const float* x, const float* dy, float* dw_kn, float* dbias, int M, int K, int N, void* ws, size_t ws_bytes,
+                               hipStream_t st) {
+  const size_t need = mla_linear_wgrad_tr_ws_bytes(M, K, N);
+  if (ws_bytes < need) {
+    mla_set_error("mla_linear_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
+    return MLA_ERR_WORKSPACE;
+  }
+  MLA_REQUIRE((size_t)M * K * 4 < 0xFFFFFFF0UL && (size_t)M * N * 4 < 0xFFFFFFF0UL, "mla_linear_wgrad_split: tensors must be < 4 GiB");
+  LwGeom g;
+  g.M = M; g.K = K; g.N = N;
+  g.tilesN = N / 192;
+  lw_plan(M, K, N, &g.pairs, &g.splits);
+  g.mtiles = cdiv(M, LW_MS);
+  g.x_bytes = (unsigned)((size_t)M * K * 4);
+  g.y_bytes = (unsigned)((size_t)M * N * 4);
+  float* part = (float*)ws;
+  float* bias_part = part + (size_t)g.splits * K * N;
+  if (dbias) linear_wgrad_tr_kernel<true><<<g.pairs * g.splits, 512, 0, st>>>(x, dy, part, bias_part, g);
+  else linear_wgrad_tr_kernel<false><<<g.pairs * g.splits, 512, 0, st>>>(x, dy, part, nullptr, g);
+  MLA_CHECK_LAUNCH("linear_wgrad_tr_kernel");
+  if (int rc = mla_wgrad_reduce(part, dw_kn, (size_t)K * N / 4, g.splits, st)) return rc;
+  return dbias ? mla_wgrad_reduce(bias_part, dbias, (size_t)N / 4, g.splits, st) : MLA_OK;
+}
+

@@ -32,7 +32,9 @@ def rel_l2(got, want):
 
 
 @pytest.mark.parametrize("groups,rows,xg,xo,yg,yo,K,N", [(1, 771, 771, 0, 771, 0, 768, 2304), (3, 256, 256, 0, 257, 1, 768, 768),
-                                                          (2, 5, 9, 3, 7, 2, 64, 128), (1, 300, 300, 0, 300, 0, 3072, 768)])
+                                                          (2, 5, 9, 3, 7, 2, 64, 128), (1, 300, 300, 0, 300, 0, 3072, 768),
+                                                          (1, 4113, 4113, 0, 4113, 0, 768, 3072),      # 128.5 row tiles of the 192 x 192 kernel
+                                                          (2, 130, 131, 1, 130, 0, 192, 384)])         # windowed rows: the per-tap kernel
 def test_linear_fwd_dgrad_wgrad(ops, groups, rows, xg, xo, yg, yo, K, N):
     seed = groups + rows + K
     x = O.portable_normal(seed, (groups, xg, K), stream=1)
@@ -81,6 +83,21 @@ def test_linear_fwd_dgrad_wgrad(ops, groups, rows, xg, xo, yg, yo, K, N):
     dw3 = torch.empty((K, N), device="cuda")
     ops.linear_wgrad(x.cuda(), dy.cuda(), dw3, ws2, groups, rows, K, N, x_group_rows=xg, x_off=xo, split=True)
     assert torch.equal(dw3, dw2), "the fused bias sums must not change the weight gradient"
+    # the 192 x 192 transposing-read kernel (dense rows, K and N multiples of 192, M >= 128) against the per-tap kernel; reproducible
+    dw4, db4 = torch.empty((K, N), device="cuda"), torch.empty(N, device="cuda")
+    ops.linear_wgrad(x.cuda(), dy.cuda(), dw4, ws2, groups, rows, K, N, x_group_rows=xg, x_off=xo, split=True, dbias=db4)
+    assert torch.equal(dw4, dw2) and torch.equal(db4, db2), "bitwise reproducible"
+    assert ops.conv2d_wgrad_tr() == 1
+    ops.conv2d_wgrad_tr(0)
+    try:
+        dw5, db5 = torch.empty((K, N), device="cuda"), torch.empty(N, device="cuda")
+        ops.linear_wgrad(x.cuda(), dy.cuda(), dw5, ws2, groups, rows, K, N, x_group_rows=xg, x_off=xo, split=True, dbias=db5)
+    finally:
+        ops.conv2d_wgrad_tr(1)
+    assert_close(dw5, xs.reshape(M, K).t() @ dy, atol=0, rtol=2e-5, name="linear wgrad (split, per-tap kernel)")
+    assert_close(db5, dy.double().sum(0), atol=2e-6 * math.sqrt(M), rtol=2e-5, name="bias grad (per-tap kernel)")
+    tr_kernel = K % 192 == 0 and N % 192 == 0 and M >= 128 and xo == 0 and (groups == 1 or xg == rows)
+    assert torch.equal(dw5, dw2) != tr_kernel, "kernel selection: the transposing-read kernel runs exactly where it is supported"
 
 
 @pytest.mark.parametrize("M,D", [(771, 768), (5, 768), (1000, 512), (130, 1024)])
