@@ -131,6 +131,9 @@ int mla_conv2d_wgrad_tr(int on);
  * input patch (conv_patch_split.hip) for the 3x3 / stride 1 / pad 1 forward and input-gradient launches whose grid fills the chip,
  * 2 = for all of them; other values: query.  Returns the setting. */
 int mla_conv2d_patch(int on);
+/* measurement / test hook: 0 = one launch per output parity class of a stride-2 input gradient (split arithmetic), 1 (default;
+ * $MLA_DGRAD_MERGE overrides) = all classes in one launch, longest K first; other values: query.  Returns the setting. */
+int mla_conv2d_dgrad_merge(int on);
 int mla_conv2d_split_terms(int terms);
 /* The ResNet stem (backbone.py:79-83, 149: 7x7, stride 2, pad 3, 1 or 3 -> 64 channels) on the split arithmetic, as persistent
  * patch-loader kernels: a workgroup keeps the weights (forward: three bf16 planes) resident in LDS, loads the 37 x 37 x Cin

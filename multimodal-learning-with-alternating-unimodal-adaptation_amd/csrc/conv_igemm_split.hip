@@ -32,12 +32,40 @@
 // BKS = K per stage: 32 (64-B LDS rows, two MFMA k-chunks per barrier) or 16 (32-B rows, one k-chunk per barrier, half
 // the LDS: two 8-wave workgroups per CU, whose prologues / epilogues / barriers then overlap each other).
 // Chunk swizzle of row r: BKS 32: 16-B chunk q -> q ^ ((r >> 2) & 3);  BKS 16: 16-B half q -> q ^ ((r >> 3) & 1).
-template <int BM, int BN, int WM, int WN, int TERMS, int BKS, int WPE>
-__global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const float* __restrict__ X, const void* __restrict__ Wsp,
-                                                                         float* Y, const float* R, const float* MASK,
-                                                                         float* __restrict__ part, const float* __restrict__ BIAS,
-                                                                         float* __restrict__ Y2, const IGemmGeom g) {
+template <int BM, int BN, int WM, int WN, int BKS>
+struct SplitTileCfg {
   static_assert(BKS == 32 || BKS == 16, "stage depth");
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  static constexpr int LR = BKS / 2;                                  // dwords per LDS row
+  static constexpr int ASZ = 3 * BM * LR, BSZ = 3 * BN * LR;          // dwords per buffer
+};
+
+template <int BM>
+__device__ __forceinline__ void fill_rowinfo(int4* rowinfo, const IGemmGeom& g, int tm, int tid, int nt) {
+  for (int r = tid; r < BM; r += nt) {
+    const int m = tm * BM + r;
+    int4 info = make_int4(-1, -100000, -100000, 0);
+    if (m < g.M) {
+      const int ohw = g.OH * g.OW;
+      const int n = m / ohw, rem = m - n * ohw;
+      const int oy = rem / g.OW, ox = rem - oy * g.OW;
+      info.x = n * g.H * g.W;
+      info.y = oy * g.sy;
+      info.z = ox * g.sx;
+      info.w = (n * g.OHF + oy * g.osy + g.ooy) * g.OWF + ox * g.osx + g.oox;
+    }
+    rowinfo[r] = info;
+  }
+}
+
+// One output tile (tm, tn) of the geometry g: rowinfo, K loop over its T * (C / BKS) stages, epilogue.  A device function so that one launch
+// can serve several geometries (igemm_split_classes_kernel: the parity classes of a stride-2 input gradient).
+template <int BM, int BN, int WM, int WN, int TERMS, int BKS>
+__device__ __forceinline__ void igemm_split_tile(const float* __restrict__ X, const void* __restrict__ Wsp, float* Y, const float* R,
+                                                 const float* MASK, float* __restrict__ part, const float* __restrict__ BIAS,
+                                                 float* __restrict__ Y2, const IGemmGeom& g, unsigned* As, unsigned* Bs, int4* rowinfo,
+                                                 int tm, int tn) {
   constexpr int NT = 64 * WM * WN;
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
   constexpr int LR = BKS / 2;                                  // dwords per LDS row
@@ -51,32 +79,11 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
   constexpr int ASZ = 3 * BM * LR, BSZ = 3 * BN * LR;          // dwords per buffer
   typedef typename std::conditional<BKS == 32, u32x4, u32x2>::type bchunk_t;
 
-  __shared__ __attribute__((aligned(16))) unsigned As[2 * ASZ];
-  __shared__ __attribute__((aligned(16))) unsigned Bs[2 * BSZ];
-  __shared__ int4 rowinfo[BM];  // {n*H*W or -1, oy*sy, ox*sx, output pixel index}
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int gridN = g.CO / BN;
-  int tm, tn;
-  tile_coords(wg, (int)gridDim.x / gridN, gridN, tm, tn);
   const int gH = g.H, gW = g.W, gC = g.C, gCO = g.CO;
 
-  for (int r = tid; r < BM; r += NT) {
-    const int m = tm * BM + r;
-    int4 info = make_int4(-1, -100000, -100000, 0);
-    if (m < g.M) {
-      const int ohw = g.OH * g.OW;
-      const int n = m / ohw, rem = m - n * ohw;
-      const int oy = rem / g.OW, ox = rem - oy * g.OW;
-      info.x = n * gH * gW;
-      info.y = oy * g.sy;
-      info.z = ox * g.sx;
-      info.w = (n * g.OHF + oy * g.osy + g.ooy) * g.OWF + ox * g.osx + g.oox;
-    }
-    rowinfo[r] = info;
-  }
+  fill_rowinfo<BM>(rowinfo, g, tm, tid, NT);
   __syncthreads();
 
   f32x16 acc[MI][NI];
@@ -239,6 +246,51 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const fl
     __syncthreads();
   }
   igemm_epilogue<BM, BN, WM, WN>(acc, rowinfo, reinterpret_cast<float*>(As), Y, R, MASK, part, BIAS, Y2, g, tm, tn);
+}
+
+template <int BM, int BN, int WM, int WN, int TERMS, int BKS, int WPE>
+__global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_kernel(const float* __restrict__ X, const void* __restrict__ Wsp,
+                                                                         float* Y, const float* R, const float* MASK,
+                                                                         float* __restrict__ part, const float* __restrict__ BIAS,
+                                                                         float* __restrict__ Y2, const IGemmGeom g) {
+  typedef SplitTileCfg<BM, BN, WM, WN, BKS> C;
+  __shared__ __attribute__((aligned(16))) unsigned As[2 * C::ASZ];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[2 * C::BSZ];
+  __shared__ int4 rowinfo[BM];  // {n*H*W or -1, oy*sy, ox*sx, output pixel index}
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int gridN = g.CO / BN;
+  int tm, tn;
+  tile_coords(wg, (int)gridDim.x / gridN, gridN, tm, tn);
+  igemm_split_tile<BM, BN, WM, WN, TERMS, BKS>(X, Wsp, Y, R, MASK, part, BIAS, Y2, g, As, Bs, rowinfo, tm, tn);
+}
+
+// The output parity classes of a stride-2 input gradient in ONE launch.  Each class is its own gather-GEMM (1, 2, 2 and 4 of the nine
+// taps of a 3x3 kernel) over a quarter of the pixels; launched one after the other, layer3.0 / layer4.0 put 128-148 workgroups on the
+// 256 CUs four times over (the kernel trace of the round-3 step: 27 + 39 + 39 + 65 us for 22 GFLOP).  Here the classes share the
+// grid, longest first (4-tap tiles, then the 2-tap ones, the 1-tap class fills the tail), so the chip stays full until the end.
+struct IGemmClasses {
+  IGemmGeom g[4];
+  const float* R[4];         // residual per class (null: none)
+  int first[5];              // first workgroup of class slot c; first[n] = grid size
+  int n;
+};
+static_assert(sizeof(IGemmClasses) + 32 <= 4096, "kernel arguments must fit the 4 KB kernarg segment");
+template <int BM, int BN, int WM, int WN, int BKS, int WPE>
+__global__ __launch_bounds__(64 * WM * WN, WPE) void igemm_split_classes_kernel(const float* __restrict__ X, const void* __restrict__ Wsp,
+                                                                                 float* Y, const float* MASK, const IGemmClasses cs) {
+  typedef SplitTileCfg<BM, BN, WM, WN, BKS> C;
+  __shared__ __attribute__((aligned(16))) unsigned As[2 * C::ASZ];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[2 * C::BSZ];
+  __shared__ int4 rowinfo[BM];
+  const int wg = (int)blockIdx.x;            // dispatch order = class order (no XCD remap across classes of different length)
+  int c = 0;
+  while (c + 1 < cs.n && wg >= cs.first[c + 1]) ++c;
+  const IGemmGeom& g = cs.g[c];
+  const int nwg = cs.first[c + 1] - cs.first[c];
+  const int gridN = g.CO / BN;
+  int tm, tn;
+  tile_coords(xcd_remap(wg - cs.first[c], nwg), nwg / gridN, gridN, tm, tn);
+  igemm_split_tile<BM, BN, WM, WN, 6, BKS>(X, Wsp, Y, cs.R[c], MASK, nullptr, nullptr, nullptr, g, As, Bs, rowinfo, tm, tn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -610,6 +662,19 @@ extern "C" int mla_conv2d_wsplit_batch(const float* params, void* wsplit, const 
   return MLA_OK;
 }
 
+static int g_dgrad_merge = -1;                        // -1: $MLA_DGRAD_MERGE (default 1)
+static bool dgrad_merge_on() {
+  if (g_dgrad_merge < 0) {
+    const char* e = getenv("MLA_DGRAD_MERGE");
+    g_dgrad_merge = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_dgrad_merge != 0;
+}
+extern "C" int mla_conv2d_dgrad_merge(int on) {       // measurement / test hook: 0 = one launch per parity class, 1 = default; other: query
+  if (on == 0 || on == 1) g_dgrad_merge = on;
+  return dgrad_merge_on() ? 1 : 0;
+}
+
 extern "C" int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float* y, int N, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad, float* bn_partial, int* bn_tiles, void* stream) {
   if (int rc = check_conv("mla_conv2d_fwd_split", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
@@ -645,6 +710,47 @@ extern "C" int mla_conv2d_dgrad_split_classes(const float* dy, const void* wspli
   MLA_REQUIRE(Cin % 64 == 0, "mla_conv2d_dgrad_split: Cin=%d must be a multiple of 64 (the stem needs no dgrad)", Cin);
   MLA_REQUIRE(dy && wsplit && dx, "mla_conv2d_dgrad_split: null pointer");
   int tiles = 0;
+  if (stride == 2 && dgrad_merge_on() && g_split_terms == 6 && g_split_cfg < 0) {
+    // all requested parity classes in one launch, longest K first
+    IGemmClasses cs;
+    cs.n = 0;
+    int order[4], nord = 0;
+    IGemmGeom gc[4];
+    for (int cls = 0; cls < 4; ++cls) {
+      if (!((class_mask >> cls) & 1)) continue;
+      make_dgrad_geom(gc[cls], cls / 2, cls % 2, N, H, W, Cin, Cout, KH, KW, stride, pad);
+      if (gc[cls].M <= 0) continue;
+      int pos = nord++;
+      while (pos > 0 && gc[order[pos - 1]].T < gc[cls].T) { order[pos] = order[pos - 1]; --pos; }
+      order[pos] = cls;
+    }
+    if (nord >= 2) {
+      const IGemmGeom& big = gc[order[0]];
+      const int cfg = pick_scfg(big.M, Cin, big.T > 0 ? big.T : 1, KH * KW == 1 ? Cout : 1 << 30);
+      const int bm = scfg_bm(cfg), bn = scfg_bn(cfg);
+      cs.first[0] = 0;
+      for (int k = 0; k < nord; ++k) {
+        const int cls = order[k];
+        cs.g[k] = gc[cls];
+        if (int rc = attach_bn_reqs("mla_conv2d_dgrad_split_bn", cs.g[k], reqs, nreq, tiles)) return rc;
+        cs.R[k] = ((residual_mask >> cls) & 1) ? residual : nullptr;
+        const int tm = cdiv(cs.g[k].M, bm);
+        cs.first[k + 1] = cs.first[k] + tm * (Cin / bn);
+        tiles += tm;
+      }
+      cs.n = nord;
+      const int grid = cs.first[nord];
+      hipStream_t st = (hipStream_t)stream;
+      if (cfg == SCFG_256x128) igemm_split_classes_kernel<256, 128, 4, 2, 32, 1><<<grid, 512, 0, st>>>(dy, wsplit, dx, relu_src, cs);
+      else if (cfg == SCFG_128x128) igemm_split_classes_kernel<128, 128, 2, 4, 32, 1><<<grid, 512, 0, st>>>(dy, wsplit, dx, relu_src, cs);
+      else if (cfg == SCFG_256x64) igemm_split_classes_kernel<256, 64, 4, 2, 16, 4><<<grid, 512, 0, st>>>(dy, wsplit, dx, relu_src, cs);
+      else if (cfg == SCFG_128x64) igemm_split_classes_kernel<128, 64, 2, 2, 32, 1><<<grid, 256, 0, st>>>(dy, wsplit, dx, relu_src, cs);
+      else igemm_split_classes_kernel<64, 64, 2, 2, 32, 1><<<grid, 256, 0, st>>>(dy, wsplit, dx, relu_src, cs);
+      MLA_CHECK_LAUNCH("igemm_split_classes_kernel");
+      if (bn_tiles) *bn_tiles = tiles;
+      return MLA_OK;
+    }
+  }
   for (int py = 0; py < stride; ++py)
     for (int px = 0; px < stride; ++px) {
       const int cls = py * stride + px;               // output parity class (py, px): bit of class_mask / residual_mask

@@ -309,6 +309,11 @@ def conv2d_patch(on: int = -1) -> int:
     return int(_lib.load().mla_conv2d_patch(int(on)))
 
 
+def conv2d_dgrad_merge(on: int = -1) -> int:
+    """Measurement hook: 0 / 1 = one launch per parity class / all classes in one launch for the stride-2 split input gradient; -1: query."""
+    return int(_lib.load().mla_conv2d_dgrad_merge(int(on)))
+
+
 def conv2d_split_terms(terms: int = 0) -> int:
     """Select (3, 6, 8) or query (anything else) the bf16 product set of the split kernels; 6 = fp32-equivalent."""
     return int(_lib.load().mla_conv2d_split_terms(int(terms)))

@@ -249,6 +249,53 @@ def test_conv_patch_fwd_dgrad(ops, case):
         assert_close(got[2][3], got[0][3], atol=2e-6 * got[0][3].abs().max().item(), rtol=2e-5, name=f"patch fused BN dx (residual={with_res})")
 
 
+@pytest.mark.parametrize("case", [(2, 20, 12, 64, 128), (3, 14, 14, 128, 256), (3, 7, 7, 256, 512), (5, 9, 11, 64, 128), (40, 28, 28, 128, 256),
+                                  (64, 16, 8, 256, 512)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_dgrad_merged_parity_classes(ops, case):
+    """Stride-2 input gradient (3x3, pad 1): the four output parity classes in one launch (igemm_split_classes_kernel, longest K first) against
+    one launch per class -- same tiles, same K order: bit-identical dx; the fused BatchNorm-backward sums agree to summation order of the
+    partial rows; class subsets with a per-class residual (the downsample fold of the encoder) included."""
+    N, H, W, Cin, Cout = case
+    seed = sum(case) + 13
+    OH, OW = ops.conv_out(H, 3, 2, 1), ops.conv_out(W, 3, 2, 1)
+    w = O.portable_normal(seed, (Cout, Cin, 3, 3), stream=2, std=math.sqrt(2.0 / (Cin * 9)))
+    dy = O.portable_normal(seed, (N, Cout, OH, OW), stream=3)
+    res = O.portable_normal(seed, (N, Cin, H, W), stream=4)
+    msk = O.portable_normal(seed, (N, Cin, H, W), stream=5)
+    z = nhwc(O.portable_normal(seed, (N, Cin, H, W), stream=6, mean=0.3, std=1.5)).cuda()
+    wd, dyd, resd, mskd = hwio(w).cuda(), nhwc(dy).cuda(), nhwc(res).cuda(), nhwc(msk).cuda()
+    wS = ops.conv2d_wsplit(wd, False)
+    M = N * H * W
+    zpart = torch.empty(ops.bn_stats_partial_elems(M, Cin), device="cuda")
+    zt = ops.bn_stats_partial(z.view(M, Cin), M, Cin, zpart)
+    mean, invstd = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    ops.bn_finalize(zpart, zt, M, Cin, mean, invstd, None, None)
+    gamma = O.portable_normal(seed, (Cin,), stream=9, mean=1.0, std=0.2).cuda()
+    assert ops.conv2d_dgrad_merge() == 1
+    got = {}
+    try:
+        for merge in (1, 0):
+            ops.conv2d_dgrad_merge(merge)
+            rpart = torch.full((ops.conv2d_dgrad_bn_partial_elems(N, H, W, Cin),), float("nan"), device="cuda")
+            dx, rt = ops.conv2d_dgrad_split(dyd, wS, wd.shape, (N, H, W, Cin), 2, 1, residual=resd, relu_src=mskd, bn_reqs=[(z, mean, invstd, rpart)])
+            o, dg, db = torch.empty_like(dx), torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+            ops.bn_bwd_from_partial(dx.view(M, Cin), z.view(M, Cin), mean, invstd, gamma, o.view(M, Cin), dg, db, rpart, rt, M, Cin)
+            # class subset: classes 1-3 only, residual on class 3 only, into a prefilled buffer (what the downsample fold launches)
+            dx2 = torch.full((N, H, W, Cin), 7.0, device="cuda")
+            ops.conv2d_dgrad_split(dyd, wS, wd.shape, (N, H, W, Cin), 2, 1, dx=dx2, residual=resd, relu_src=mskd, class_mask=0xE, residual_mask=0x8)
+            torch.cuda.synchronize()
+            got[merge] = (dx, dg, db, o, dx2)
+    finally:
+        ops.conv2d_dgrad_merge(1)
+    assert torch.equal(got[1][0], got[0][0]), "merged launch: dx must not change"
+    assert torch.equal(got[1][4], got[0][4]), "merged launch of a class subset"
+    assert torch.all(got[1][4][:, 0::2, 0::2] == 7.0), "class (0, 0) was not requested: its pixels stay untouched"
+    dx_ref = (O.conv2d_dgrad(dy, w, (N, Cin, H, W), 2, 1) + res) * (msk > 0) if M * Cin < 1_500_000 else nchw(got[0][0].cpu())
+    assert_close(nchw(got[1][0].cpu()), dx_ref, atol=0, rtol=2e-5, name="merged stride-2 dgrad")
+    for k, nm in ((1, "dgamma"), (2, "dbeta"), (3, "BN dx")):
+        assert_close(got[1][k], got[0][k], atol=2e-6 * got[0][k].abs().max().item(), name=f"merged launch fused {nm}")
+
+
 STEM_CASES = [
     # N, H, W, Cin: the 7x7 / 2 / 3 stem (backbone.py:79-83) on the persistent split-arithmetic kernels (stem_split.hip)
     (2, 40, 24, 1),        # audio, ragged tiles (OH x OW = 20 x 12)
