@@ -22,7 +22,7 @@
 // {0-3,12-15,20-27}, ...) and the staging stores conflict-free.
 #define LROW 16
 #ifndef SPLIT_EFF
-#define SPLIT_EFF 1.0, 0.95, 0.8, 0.7, 0.9
+#define SPLIT_EFF 1.0, 0.95, 0.8, 0.7, 0.9, 0.93
 #endif
 
 // One workgroup of WM x WN waves per CU, two LDS buffers, one barrier per K step: while the MFMAs of K step `it`
@@ -563,13 +563,13 @@ extern "C" int mla_conv2d_split_terms(int terms) {   // measurement hook: 3, 6 (
   return g_split_terms;
 }
 
-// Tiles: 256x128 and 128x128 (8 waves, K stage 32, one workgroup per CU), 256x64 (8 waves, K stage 16, two per CU:
+// Tiles: 256x128, 192x128 (96x32 wave tiles: for row counts that leave 256-row tiles on ~half of the CUs, e.g. 9 408 = 49 x 192) and 128x128 (8 waves, K stage 32, one workgroup per CU), 256x64 (8 waves, K stage 16, two per CU:
 // the Cout = 64 layers, +10 % over 128x64), 128x64 and 64x64 (4 waves, K stage 32, two / three per CU).  Measured the other
 // way round too: 128x128 at K stage 16 with two workgroups per CU is 6-15 % slower than one at K stage 32, 256x64 at
 // K stage 32 (one per CU) 5-15 % slower than two at K stage 16.
-enum { SCFG_256x128 = 0, SCFG_128x128 = 1, SCFG_128x64 = 2, SCFG_64x64 = 3, SCFG_256x64 = 4, SCFG_COUNT = 5 };
-static int scfg_bm(int c) { return (c == SCFG_256x128 || c == SCFG_256x64) ? 256 : (c == SCFG_64x64 ? 64 : 128); }
-static int scfg_bn(int c) { return c <= SCFG_128x128 ? 128 : 64; }
+enum { SCFG_256x128 = 0, SCFG_128x128 = 1, SCFG_128x64 = 2, SCFG_64x64 = 3, SCFG_256x64 = 4, SCFG_192x128 = 5, SCFG_COUNT = 6 };
+static int scfg_bm(int c) { return (c == SCFG_256x128 || c == SCFG_256x64) ? 256 : (c == SCFG_64x64 ? 64 : (c == SCFG_192x128 ? 192 : 128)); }
+static int scfg_bn(int c) { return (c <= SCFG_128x128 || c == SCFG_192x128) ? 128 : 64; }
 static int g_split_cfg = -1;   // measurement hook: force one tile
 extern "C" int mla_conv2d_split_cfg(int cfg) { g_split_cfg = (cfg >= 0 && cfg < SCFG_COUNT) ? cfg : -1; return g_split_cfg; }
 
@@ -582,7 +582,7 @@ static int pick_scfg(long M, int CO, int weight, int k_total = 1 << 30) {
   // dominate, the 64x64 tile with three workgroups per CU is fastest at every such shape (forced-tile probe, 10-45 % over the model)
   if (k_total <= 512 && M <= (1L << 18)) return SCFG_64x64;
   const double eff[SCFG_COUNT] = {SPLIT_EFF};
-  const int per_cu_tab[SCFG_COUNT] = {1, 1, 2, 3, 2};            // resident workgroups per CU (LDS / VGPRs)
+  const int per_cu_tab[SCFG_COUNT] = {1, 1, 2, 3, 2, 1};         // resident workgroups per CU (LDS / VGPRs)
   int best = -1;
   double best_cost = 0;
   for (int c = 0; c < SCFG_COUNT; ++c) {
@@ -625,6 +625,7 @@ static void launch_split_t(int cfg, int total, hipStream_t st, const float* X, c
   if (cfg == SCFG_256x128) igemm_split_kernel<256, 128, 4, 2, TERMS, 32, 1><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
   else if (cfg == SCFG_128x128) igemm_split_kernel<128, 128, 2, 4, TERMS, 32, 1><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
   else if (cfg == SCFG_256x64) igemm_split_kernel<256, 64, 4, 2, TERMS, 16, 4><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
+  else if (cfg == SCFG_192x128) igemm_split_kernel<192, 128, 2, 4, TERMS, 32, 1><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
   else if (cfg == SCFG_128x64) igemm_split_kernel<128, 64, 2, 2, TERMS, 32, 1><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
   else igemm_split_kernel<64, 64, 2, 2, TERMS, 32, 1><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
 }
@@ -744,6 +745,7 @@ extern "C" int mla_conv2d_dgrad_split_classes(const float* dy, const void* wspli
       if (cfg == SCFG_256x128) igemm_split_classes_kernel<256, 128, 4, 2, 32, 1><<<grid, 512, 0, st>>>(dy, wsplit, dx, relu_src, cs);
       else if (cfg == SCFG_128x128) igemm_split_classes_kernel<128, 128, 2, 4, 32, 1><<<grid, 512, 0, st>>>(dy, wsplit, dx, relu_src, cs);
       else if (cfg == SCFG_256x64) igemm_split_classes_kernel<256, 64, 4, 2, 16, 4><<<grid, 512, 0, st>>>(dy, wsplit, dx, relu_src, cs);
+      else if (cfg == SCFG_192x128) igemm_split_classes_kernel<192, 128, 2, 4, 32, 1><<<grid, 512, 0, st>>>(dy, wsplit, dx, relu_src, cs);
       else if (cfg == SCFG_128x64) igemm_split_classes_kernel<128, 64, 2, 2, 32, 1><<<grid, 256, 0, st>>>(dy, wsplit, dx, relu_src, cs);
       else igemm_split_classes_kernel<64, 64, 2, 2, 32, 1><<<grid, 256, 0, st>>>(dy, wsplit, dx, relu_src, cs);
       MLA_CHECK_LAUNCH("igemm_split_classes_kernel");
