@@ -134,6 +134,10 @@ int mla_conv2d_patch(int on);
 /* measurement / test hook: 0 = one launch per output parity class of a stride-2 input gradient (split arithmetic), 1 (default;
  * $MLA_DGRAD_MERGE overrides) = all classes in one launch, longest K first; other values: query.  Returns the setting. */
 int mla_conv2d_dgrad_merge(int on);
+/* measurement / test hook: 0 = every split forward / input-gradient gather-GEMM is one launch, 1 (default; $MLA_CONV_TWO_PHASE overrides) =
+ * row counts between whole rounds of the 256 CUs run whole rounds of a big tile and one launch of the best tile for the remaining rows;
+ * other values: query.  Results do not depend on the setting (same K order per output element). */
+int mla_conv2d_two_phase(int on);
 int mla_conv2d_split_terms(int terms);
 /* The ResNet stem (backbone.py:79-83, 149: 7x7, stride 2, pad 3, 1 or 3 -> 64 channels) on the split arithmetic, as persistent
  * patch-loader kernels: a workgroup keeps the weights (forward: three bf16 planes) resident in LDS, loads the 37 x 37 x Cin

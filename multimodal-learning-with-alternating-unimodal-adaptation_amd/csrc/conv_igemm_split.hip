@@ -44,7 +44,7 @@ struct SplitTileCfg {
 template <int BM>
 __device__ __forceinline__ void fill_rowinfo(int4* rowinfo, const IGemmGeom& g, int tm, int tid, int nt) {
   for (int r = tid; r < BM; r += nt) {
-    const int m = tm * BM + r;
+    const int m = g.m0 + tm * BM + r;
     int4 info = make_int4(-1, -100000, -100000, 0);
     if (m < g.M) {
       const int ohw = g.OH * g.OW;
@@ -630,15 +630,83 @@ static void launch_split_t(int cfg, int total, hipStream_t st, const float* X, c
   else igemm_split_kernel<64, 64, 2, 2, TERMS, 32, 1><<<total, 256, 0, st>>>(X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
 }
 
-static int launch_split(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part,
-                        const IGemmGeom& mg, int cfg, hipStream_t st, const float* BIAS = nullptr, float* Y2 = nullptr) {
-  const int total = cdiv(mg.M, scfg_bm(cfg)) * (mg.CO / scfg_bn(cfg));
+static double scfg_cost(int c, long M, int CO) {       // the cost of pick_scfg: rounds x resident workgroups x tile area / relative rate
+  const double eff[SCFG_COUNT] = {SPLIT_EFF};
+  const int per_cu_tab[SCFG_COUNT] = {1, 1, 2, 3, 2, 1};
+  const double blocks = (double)cdiv(M, scfg_bm(c)) * (CO / scfg_bn(c));
+  const int per_cu = per_cu_tab[c];
+  const double rounds = (double)((long)((blocks + 256 * per_cu - 1) / (256 * per_cu)));
+  return rounds * per_cu * scfg_bm(c) * scfg_bn(c) / eff[c];
+}
+
+// Two-phase schedule for row counts between whole rounds (visual layer3: 37 632 rows x 256 columns = 2.3 rounds of 128x128 tiles, 1.5 of
+// 192x128 ones -- every single tile shape pays for a mostly empty last round): whole rounds of a big tile over the first rows, then ONE
+// launch of the best tile for the rows that are left (24 576 rows as 256 tiles of 192x128 + 13 056 rows as 204 tiles of 128x128: 1.25 instead
+// of 1.5 tile-round units).  Each output row belongs to exactly one launch; statistics rows of the second launch follow the first's.
+static int g_two_phase = -1;                          // -1: $MLA_CONV_TWO_PHASE (default 1)
+extern "C" int mla_conv2d_two_phase(int on) {         // measurement / test hook: 0 = always one launch, 1 = default; other: query
+  if (on == 0 || on == 1) g_two_phase = on;
+  if (g_two_phase < 0) { const char* e = getenv("MLA_CONV_TWO_PHASE"); g_two_phase = (e && e[0] == '0') ? 0 : 1; }
+  return g_two_phase;
+}
+static bool plan_two_phase(const IGemmGeom& g, int cfg1, int k_stages, int* cfgA, int* rowsA, int* cfgB) {
+  if (!mla_conv2d_two_phase(-1) || g_split_cfg >= 0 || g.CO % 128 != 0 || g.m0 != 0 || k_stages < 16) return false;
+  const double eff[SCFG_COUNT] = {SPLIT_EFF};
+  double best = 0.93 * scfg_cost(cfg1, g.M, g.CO);
+  bool found = false;
+  const int gridN = g.CO / 128;
+  if (256 % gridN != 0) return false;
+  const int bigs[2] = {SCFG_256x128, SCFG_192x128};
+  for (int k = 0; k < 2; ++k) {
+    const int cA = bigs[k];
+    const long rows_round = (long)(256 / gridN) * scfg_bm(cA);
+    const long full = g.M / rows_round;
+    const long rA = full * rows_round, rem = g.M - rA;
+    if (full < 1 || rem <= 0) continue;
+    const double costA = (double)full * scfg_bm(cA) * 128 / eff[cA];
+    int cB = -1;
+    double costB = 0;
+    for (int c = 0; c < SCFG_COUNT; ++c) {
+      if (g.CO % scfg_bn(c) != 0) continue;
+      const double cc = scfg_cost(c, rem, g.CO);
+      if (cB < 0 || cc < costB) { cB = c; costB = cc; }
+    }
+    const double total = costA + costB + 0.03 * 256 * 128;
+    if (total < best) { best = total; *cfgA = cA; *rowsA = (int)rA; *cfgB = cB; found = true; }
+  }
+  return found;
+}
+
+static int launch_split_one(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part,
+                            const IGemmGeom& mg, int cfg, hipStream_t st, const float* BIAS, float* Y2) {
+  const int total = cdiv(mg.M - mg.m0, scfg_bm(cfg)) * (mg.CO / scfg_bn(cfg));
   if (total <= 0) return MLA_OK;
   if (g_split_terms == 6) launch_split_t<6>(cfg, total, st, X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
   else if (g_split_terms == 8) launch_split_t<8>(cfg, total, st, X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
   else launch_split_t<3>(cfg, total, st, X, Wsp, Y, R, MASK, part, BIAS, Y2, mg);
   MLA_CHECK_LAUNCH("igemm_split_kernel");
   return MLA_OK;
+}
+
+// row_tiles (optional): number of statistics rows ([tile][2][CO]) the launch(es) wrote / advanced
+static int launch_split(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part,
+                        const IGemmGeom& mg, int cfg, hipStream_t st, const float* BIAS = nullptr, float* Y2 = nullptr,
+                        int* row_tiles = nullptr) {
+  int cfgA, rowsA, cfgB;
+  if (!BIAS && !Y2 && plan_two_phase(mg, cfg, mg.T * (mg.C / 32), &cfgA, &rowsA, &cfgB)) {
+    IGemmGeom ga = mg;
+    ga.M = rowsA;
+    if (int rc = launch_split_one(X, Wsp, Y, R, MASK, part, ga, cfgA, st, nullptr, nullptr)) return rc;
+    const int tilesA = rowsA / scfg_bm(cfgA);
+    IGemmGeom gb = mg;
+    gb.m0 = rowsA;
+    gb.bn_tile0 = mg.bn_tile0 + tilesA;
+    float* partB = part ? part + (size_t)tilesA * 2 * mg.CO * 2 : nullptr;       // fp64 rows [tile][2][CO]
+    if (row_tiles) *row_tiles = tilesA + cdiv(mg.M - rowsA, scfg_bm(cfgB));
+    return launch_split_one(X, Wsp, Y, R, MASK, partB, gb, cfgB, st, nullptr, nullptr);
+  }
+  if (row_tiles) *row_tiles = cdiv(mg.M, scfg_bm(cfg));
+  return launch_split_one(X, Wsp, Y, R, MASK, part, mg, cfg, st, BIAS, Y2);
 }
 
 extern "C" size_t mla_conv2d_wsplit_bytes(int Cin, int Cout, int KH, int KW) {
@@ -686,8 +754,7 @@ extern "C" int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float*
   MLA_REQUIRE(g.OH > 0 && g.OW > 0, "mla_conv2d_fwd_split: empty output");
   if (use_patch(g)) return mla_patch_launch(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, bn_tiles, (hipStream_t)stream);
   const int cfg = pick_scfg(g.M, Cout, 1, KH * KW * Cin);
-  if (bn_tiles) *bn_tiles = cdiv(g.M, scfg_bm(cfg));
-  return launch_split(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, cfg, (hipStream_t)stream);
+  return launch_split(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, cfg, (hipStream_t)stream, nullptr, nullptr, bn_tiles);
 }
 
 extern "C" int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
@@ -769,8 +836,9 @@ extern "C" int mla_conv2d_dgrad_split_classes(const float* dy, const void* wspli
         continue;
       }
       const int cfg = pick_scfg(g.M, Cin, g.T > 0 ? g.T : 1, KH * KW == 1 ? Cout : 1 << 30);
-      if (int rc = launch_split(dy, wsplit, dx, res, relu_src, nullptr, g, cfg, (hipStream_t)stream)) return rc;
-      tiles += cdiv(g.M, scfg_bm(cfg));
+      int rt = 0;
+      if (int rc = launch_split(dy, wsplit, dx, res, relu_src, nullptr, g, cfg, (hipStream_t)stream, nullptr, nullptr, &rt)) return rc;
+      tiles += rt;
     }
   if (bn_tiles) *bn_tiles = tiles;
   return MLA_OK;

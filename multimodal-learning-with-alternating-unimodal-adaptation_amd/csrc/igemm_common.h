@@ -28,6 +28,7 @@ struct IGemmGeom {
   const float* bn_invstd[2];
   float* bn_part[2];
   int bn_tile0;
+  int m0;                  // first output row of this launch (split kernels: a launch may cover the row window [m0, M) of the problem)
 };
 
 // Gathers use raw buffer loads: the hardware range check of the buffer descriptor returns 0 for any

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "mla_conv2d_wgrad_tr": (_I, [_I]),
     "mla_conv2d_patch": (_I, [_I]),
     "mla_conv2d_dgrad_merge": (_I, [_I]),
+    "mla_conv2d_two_phase": (_I, [_I]),
     "mla_conv2d_split_terms": (_I, [_I]),
     "mla_conv2d_stem_supported": (_I, [_I] * 6),
     "mla_conv2d_stem_waves": (_I, [_I]),

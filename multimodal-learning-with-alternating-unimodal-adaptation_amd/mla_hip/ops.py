@@ -314,6 +314,11 @@ def conv2d_dgrad_merge(on: int = -1) -> int:
     return int(_lib.load().mla_conv2d_dgrad_merge(int(on)))
 
 
+def conv2d_two_phase(on: int = -1) -> int:
+    """Measurement hook: 0 / 1 = single launch / whole rounds of a big tile + one launch for the remaining rows (split gather-GEMM); -1: query."""
+    return int(_lib.load().mla_conv2d_two_phase(int(on)))
+
+
 def conv2d_split_terms(terms: int = 0) -> int:
     """Select (3, 6, 8) or query (anything else) the bf16 product set of the split kernels; 6 = fp32-equivalent."""
     return int(_lib.load().mla_conv2d_split_terms(int(terms)))

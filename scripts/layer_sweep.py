@@ -9,6 +9,8 @@ math = os.environ.get("MATH", "split")
 B = int(os.environ.get("B", "64"))
 if "MLA_PATCH" in os.environ:                      # same-box A/B switches of the round-3 kernels
     ops.conv2d_patch(int(os.environ["MLA_PATCH"]))
+if "MLA_CONV_TWO_PHASE" in os.environ:
+    ops.conv2d_two_phase(int(os.environ["MLA_CONV_TWO_PHASE"]))
 if "MLA_DGRAD_MERGE" in os.environ:
     ops.conv2d_dgrad_merge(int(os.environ["MLA_DGRAD_MERGE"]))
 if "MLA_WGRAD_TR" in os.environ:

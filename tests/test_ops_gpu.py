@@ -296,6 +296,56 @@ def test_conv_dgrad_merged_parity_classes(ops, case):
         assert_close(got[1][k], got[0][k], atol=2e-6 * got[0][k].abs().max().item(), name=f"merged launch fused {nm}")
 
 
+@pytest.mark.parametrize("case", [(48, 28, 28, 256, 256, True), (50, 28, 28, 256, 256, True), (70, 28, 28, 128, 128, False)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_two_phase_launch(ops, case):
+    """Row counts between whole rounds of the CUs: whole rounds of a big tile + one launch of the best tile for the remaining rows
+    (plan_two_phase) against the single launch -- every output element sees the same K order: bit-identical y / dx; the statistics rows of the
+    second launch follow the first's (fp64 BatchNorm statistics of the forward, BatchNorm-backward sums of the input gradient)."""
+    N, H, W, Cin, Cout, expect = case         # expect: the planner splits this shape (37 632 / 39 200 rows x 256 columns); 215 tiles of 256x128 fit one round
+    seed = sum(case[:5]) + 17
+    M = N * H * W
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    xd = torch.randn((N, H, W, Cin), device="cuda", generator=g)
+    wd = torch.randn((3, 3, Cin, Cout), device="cuda", generator=g) * math.sqrt(2.0 / (Cin * 9))
+    dyd = torch.randn((N, H, W, Cout), device="cuda", generator=g)
+    resd = torch.randn((N, H, W, Cin), device="cuda", generator=g)
+    mskd = torch.randn((N, H, W, Cin), device="cuda", generator=g)
+    z = torch.randn((N, H, W, Cin), device="cuda", generator=g) * 1.5 + 0.3
+    wT, wS = ops.conv2d_wsplit(wd, True), ops.conv2d_wsplit(wd, False)
+    zpart = torch.empty(ops.bn_stats_partial_elems(M, Cin), device="cuda")
+    zt = ops.bn_stats_partial(z.view(M, Cin), M, Cin, zpart)
+    mean, invstd = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    ops.bn_finalize(zpart, zt, M, Cin, mean, invstd, None, None)
+    gamma = torch.randn((Cin,), device="cuda", generator=g) * 0.2 + 1.0
+    default_patch = ops.conv2d_patch()
+    assert ops.conv2d_two_phase() == 1
+    got = {}
+    try:
+        ops.conv2d_patch(0)
+        for tp in (1, 0):
+            ops.conv2d_two_phase(tp)
+            part = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, Cin, Cout, 3, 3, 1, 1), device="cuda")
+            y, tiles = ops.conv2d_fwd_split(xd, wT, wd.shape, 1, 1, bn_partial=part)
+            pt = part.view(torch.float64)[:tiles * 2 * Cout].view(tiles, 2, Cout).sum(0)
+            rpart = torch.full((ops.conv2d_dgrad_bn_partial_elems(N, H, W, Cin),), float("nan"), device="cuda")
+            dx, rt = ops.conv2d_dgrad_split(dyd, wS, wd.shape, xd.shape, 1, 1, residual=resd, relu_src=mskd, bn_reqs=[(z, mean, invstd, rpart)])
+            o, dg, db = torch.empty_like(dx), torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+            ops.bn_bwd_from_partial(dx.view(M, Cin), z.view(M, Cin), mean, invstd, gamma, o.view(M, Cin), dg, db, rpart, rt, M, Cin)
+            torch.cuda.synchronize()
+            got[tp] = (y, tiles, pt, dx, dg, db, rt)
+    finally:
+        ops.conv2d_two_phase(1)
+        ops.conv2d_patch(default_patch)
+    assert (got[1][1] != got[0][1]) == expect and (got[1][6] != got[0][6]) == expect, "two-phase schedule: statistics-row count tells whether it ran"
+    assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][3], got[0][3]), "two launches: y / dx must not change"
+    yd = got[1][0].double().reshape(-1, Cout)
+    assert_close(got[1][2][0], yd.sum(0), atol=1e-6, rtol=1e-9, name="two-phase fused colsum == sums of the stored y")
+    assert_close(got[1][2][1], (yd ** 2).sum(0), atol=1e-6, rtol=1e-9, name="two-phase fused colsumsq")
+    assert_close(got[1][4], got[0][4], atol=2e-6 * got[0][4].abs().max().item(), name="two-phase fused dgamma")
+    assert_close(got[1][5], got[0][5], atol=2e-6 * got[0][5].abs().max().item(), name="two-phase fused dbeta")
+
+
 STEM_CASES = [
     # N, H, W, Cin: the 7x7 / 2 / 3 stem (backbone.py:79-83) on the persistent split-arithmetic kernels (stem_split.hip)
     (2, 40, 24, 1),        # audio, ragged tiles (OH x OW = 20 x 12)
