@@ -655,14 +655,16 @@ static bool plan_two_phase(const IGemmGeom& g, int cfg1, int k_stages, int* cfgA
   double best = 0.93 * scfg_cost(cfg1, g.M, g.CO);
   bool found = false;
   const int gridN = g.CO / 128;
-  if (256 % gridN != 0) return false;
   const int bigs[2] = {SCFG_256x128, SCFG_192x128};
   for (int k = 0; k < 2; ++k) {
     const int cA = bigs[k];
-    const long rows_round = (long)(256 / gridN) * scfg_bm(cA);
-    const long full = g.M / rows_round;
-    const long rA = full * rows_round, rem = g.M - rA;
-    if (full < 1 || rem <= 0) continue;
+    const long tiles = (long)cdiv(g.M, scfg_bm(cA)) * gridN;
+    const long full = tiles / 256;                                     // whole rounds of the 256 CUs
+    // whole ROW tiles that fit those rounds (wide outputs -- the transformer Linears' 6 / 18 / 24 column tiles -- leave up to
+    // gridN - 1 workgroup slots of the last round empty)
+    const long row_tiles = full * 256 / gridN;
+    const long rA = row_tiles * scfg_bm(cA), rem = g.M - rA;
+    if (full < 1 || row_tiles < 1 || rem <= 0) continue;
     const double costA = (double)full * scfg_bm(cA) * 128 / eff[cA];
     int cB = -1;
     double costB = 0;
@@ -693,17 +695,17 @@ static int launch_split(const float* X, const void* Wsp, float* Y, const float* 
                         const IGemmGeom& mg, int cfg, hipStream_t st, const float* BIAS = nullptr, float* Y2 = nullptr,
                         int* row_tiles = nullptr) {
   int cfgA, rowsA, cfgB;
-  if (!BIAS && !Y2 && plan_two_phase(mg, cfg, mg.T * (mg.C / 32), &cfgA, &rowsA, &cfgB)) {
+  if (plan_two_phase(mg, cfg, mg.T * (mg.C / 32), &cfgA, &rowsA, &cfgB)) {
     IGemmGeom ga = mg;
     ga.M = rowsA;
-    if (int rc = launch_split_one(X, Wsp, Y, R, MASK, part, ga, cfgA, st, nullptr, nullptr)) return rc;
+    if (int rc = launch_split_one(X, Wsp, Y, R, MASK, part, ga, cfgA, st, BIAS, Y2)) return rc;
     const int tilesA = rowsA / scfg_bm(cfgA);
     IGemmGeom gb = mg;
     gb.m0 = rowsA;
     gb.bn_tile0 = mg.bn_tile0 + tilesA;
     float* partB = part ? part + (size_t)tilesA * 2 * mg.CO * 2 : nullptr;       // fp64 rows [tile][2][CO]
     if (row_tiles) *row_tiles = tilesA + cdiv(mg.M - rowsA, scfg_bm(cfgB));
-    return launch_split_one(X, Wsp, Y, R, MASK, partB, gb, cfgB, st, nullptr, nullptr);
+    return launch_split_one(X, Wsp, Y, R, MASK, partB, gb, cfgB, st, BIAS, Y2);
   }
   if (row_tiles) *row_tiles = cdiv(mg.M, scfg_bm(cfg));
   return launch_split_one(X, Wsp, Y, R, MASK, part, mg, cfg, st, BIAS, Y2);

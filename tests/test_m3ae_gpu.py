@@ -34,7 +34,9 @@ def rel_l2(got, want):
 @pytest.mark.parametrize("groups,rows,xg,xo,yg,yo,K,N", [(1, 771, 771, 0, 771, 0, 768, 2304), (3, 256, 256, 0, 257, 1, 768, 768),
                                                           (2, 5, 9, 3, 7, 2, 64, 128), (1, 300, 300, 0, 300, 0, 3072, 768),
                                                           (1, 4113, 4113, 0, 4113, 0, 768, 3072),      # 128.5 row tiles of the 192 x 192 kernel
-                                                          (2, 130, 131, 1, 130, 0, 192, 384)])         # windowed rows: the per-tap kernel
+                                                          (2, 130, 131, 1, 130, 0, 192, 384),          # windowed rows: the per-tap kernel
+                                                          (64, 257, 257, 0, 257, 0, 768, 768),         # M3AE size (16 448 rows): two-phase launch,
+                                                          (64, 257, 257, 0, 257, 0, 768, 3072)])       # ... with 64 rows left for the second launch
 def test_linear_fwd_dgrad_wgrad(ops, groups, rows, xg, xo, yg, yo, K, N):
     seed = groups + rows + K
     x = O.portable_normal(seed, (groups, xg, K), stream=1)
@@ -54,6 +56,28 @@ def test_linear_fwd_dgrad_wgrad(ops, groups, rows, xg, xo, yg, yo, K, N):
     y2 = torch.empty((groups, yg, N), device="cuda")
     ops.linear_fwd(x.cuda(), w_kn, b.cuda(), y2, groups, rows, K, N, x_group_rows=xg, x_off=xo, y_group_rows=yg, y_off=yo, residual=res.cuda())
     assert_close(y2[:, yo:yo + rows], u_ref + res[:, yo:yo + rows], atol=0, rtol=2e-5, name="linear fwd + residual")
+    # the same on the split arithmetic; M3AE-sized row counts run the two-phase launch (whole rounds of 256x128 tiles + one launch for the
+    # remaining rows): bias / GELU second output / residual go through both launches; bit-identical to the single launch
+    wT, wS = ops.conv2d_wsplit(w_kn.view(1, 1, K, N), True), ops.conv2d_wsplit(w_kn.view(1, 1, K, N), False)
+    outs = {}
+    assert ops.conv2d_two_phase() == 1
+    try:
+        for tp in (1, 0):
+            ops.conv2d_two_phase(tp)
+            ys, ygs = torch.full((groups, yg, N), 7.0, device="cuda"), torch.empty((groups, yg, N), device="cuda")
+            ops.linear_fwd(x.cuda(), w_kn, b.cuda(), ys, groups, rows, K, N, x_group_rows=xg, x_off=xo, y_group_rows=yg, y_off=yo, y_gelu=ygs, wsplit=wT)
+            ys2 = torch.empty((groups, yg, N), device="cuda")
+            ops.linear_fwd(x.cuda(), w_kn, b.cuda(), ys2, groups, rows, K, N, x_group_rows=xg, x_off=xo, y_group_rows=yg, y_off=yo, residual=res.cuda(), wsplit=wT)
+            outs[tp] = (ys, ygs, ys2)
+    finally:
+        ops.conv2d_two_phase(1)
+    for a_, b_ in zip(outs[1], outs[0]):
+        assert torch.equal(a_[:, yo:yo + rows], b_[:, yo:yo + rows]), "two-phase launch: same bits as the single launch"
+    assert_close(outs[1][0][:, yo:yo + rows], u_ref, atol=0, rtol=2e-5, name="linear fwd (split)")
+    assert_close(outs[1][1][:, yo:yo + rows], F.gelu(u_ref), atol=1e-6, rtol=2e-5, name="linear fwd gelu output (split)")
+    assert_close(outs[1][2][:, yo:yo + rows], u_ref + res[:, yo:yo + rows], atol=0, rtol=2e-5, name="linear fwd + residual (split)")
+    if yo > 0:
+        assert torch.all(outs[1][0][:, :yo] == 7.0), "rows outside the window must stay untouched (split)"
     # backward (dense rows)
     M = groups * rows
     dy = O.portable_normal(seed, (M, N), stream=5)
@@ -67,6 +91,17 @@ def test_linear_fwd_dgrad_wgrad(ops, groups, rows, xg, xo, yg, yo, K, N):
     assert_close(dx, dx_ref, atol=0, rtol=2e-5, name="linear dgrad")
     ops.linear_dgrad(dy.cuda(), w_kn, dx, wt, 1, M, K, N, residual=addr.cuda(), gelu_src=usrc.cuda())
     assert_close(dx, (dx_ref + addr) * gp, atol=1e-6, rtol=2e-5, name="linear dgrad + residual, * gelu'")
+    dxs = {}
+    try:
+        for tp in (1, 0):
+            ops.conv2d_two_phase(tp)
+            d_ = torch.empty((M, K), device="cuda")
+            ops.linear_dgrad(dy.cuda(), w_kn, d_, None, 1, M, K, N, residual=addr.cuda(), gelu_src=usrc.cuda(), wsplit=wS)
+            dxs[tp] = d_
+    finally:
+        ops.conv2d_two_phase(1)
+    assert torch.equal(dxs[1], dxs[0]), "two-phase launch (input gradient): same bits as the single launch"
+    assert_close(dxs[1], (dx_ref + addr) * gp, atol=1e-6, rtol=2e-5, name="linear dgrad + residual, * gelu' (split)")
     dw = torch.empty((K, N), device="cuda")
     ws = torch.empty(ops.linear_wgrad_ws_bytes(M, K, N) // 4 + 4, device="cuda")
     ops.linear_wgrad(x.cuda(), dy.cuda(), dw, ws, groups, rows, K, N, x_group_rows=xg, x_off=xo)
