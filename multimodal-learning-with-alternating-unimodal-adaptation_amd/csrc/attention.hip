@@ -188,7 +188,10 @@ __device__ __forceinline__ float vec_wsum(const float* __restrict__ tile, float 
 // forward: workgroup = 128 queries of one (b, h); loop over key tiles of 32.  o (B, n, H*64), lse (B, H, n).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int W, int TAIL>
-__global__ __launch_bounds__(64 * W, W >= 3 ? 3 : 2) void attn_fwd_kernel(const AttGeom g, float* __restrict__ O, float* __restrict__ LSE) {
+// (with remainder rows the kernel needs ~190 VGPRs: at three 4-wave workgroups per CU it spilled 11 registers whose reloads wait `vmcnt(0)`
+//  inside the key loop; two workgroups per CU and no scratch is faster -- n = 257: 170 -> see DESIGN 8)
+__global__ __launch_bounds__(64 * W, (W >= 3 && !TAIL) ? 3 : 2) void attn_fwd_kernel(const AttGeom g, float* __restrict__ O, float* __restrict__ LSE) {
+  constexpr int TMAX = TAIL > 0 ? TAIL : 1;      // remainder rows this instantiation can own (TAIL = 1: the [cls] + 256 case, 3: any)
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 32 * ATT_LD + 2 * 32];
   float* Ks = smem;                       // [2][32][ATT_LD]
   float* Vs = smem + 2 * 32 * ATT_LD;     // [2][32][ATT_LD]
@@ -209,9 +212,9 @@ __global__ __launch_bounds__(64 * W, W >= 3 ? 3 : 2) void attn_fwd_kernel(const 
   __shared__ __attribute__((aligned(16))) float vecQ[ATT_TAIL_MAX][ATT_HD];
   __shared__ float vred[W][ATT_TAIL_MAX][ATT_HD + 2], tailSt[ATT_TAIL_MAX];
   const int nt = g.n - g.nm;
-  float vm[ATT_TAIL_MAX], vl[ATT_TAIL_MAX], vo[ATT_TAIL_MAX];
+  float vm[TMAX], vl[TMAX], vo[TMAX];
 #pragma unroll
-  for (int t = 0; t < ATT_TAIL_MAX; ++t) { vm[t] = -INFINITY; vl[t] = 0.f; vo[t] = 0.f; }
+  for (int t = 0; t < TMAX; ++t) { vm[t] = -INFINITY; vl[t] = 0.f; vo[t] = 0.f; }
   const size_t rs = (size_t)3 * g.H * ATT_HD;                  // token stride inside qkv
   const float* Qb = g.qkv + qkv_off(g, b, 0, 0, h);
   const float* Kb = g.qkv + qkv_off(g, b, 0, 1, h);
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64 * W, W >= 3 ? 3 : 2) void attn_fwd_kernel(const 
       const float* vt = Vs + cur * 32 * ATT_LD;
       const float st = Kst[cur * 32 + (lane & 31)];
 #pragma unroll
-      for (int t = 0; t < ATT_TAIL_MAX; ++t)
+      for (int t = 0; t < TMAX; ++t)
         if (t < nt) {
           float sv = vec_row_dot(kt, vecQ[t], lane);
           sv = st == 0.f ? sv * g.scale : (st == 1.f ? -1e7f : -INFINITY);
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64 * W, W >= 3 ? 3 : 2) void attn_fwd_kernel(const 
   }
   if (vec) {        // remainder queries: wave 0 adds the remainder keys to its partial, all partials are merged, wave 0 writes the rows
 #pragma unroll
-    for (int t = 0; t < ATT_TAIL_MAX; ++t)
+    for (int t = 0; t < TMAX; ++t)
       if (t < nt) {
         if (wave == 0)
           for (int j = g.nm; j < g.n; ++j) {
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(64 * W, W >= 3 ? 3 : 2) void attn_fwd_kernel(const 
     __syncthreads();
     if (wave == 0)
 #pragma unroll
-      for (int t = 0; t < ATT_TAIL_MAX; ++t)
+      for (int t = 0; t < TMAX; ++t)
         if (t < nt) {
           float m = -INFINITY;
 #pragma unroll
@@ -376,6 +379,7 @@ template <int W, int TAIL>
 __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g, const float* __restrict__ dO, const float* __restrict__ O,
                                                            const float* __restrict__ LSE, float* __restrict__ Dvec,
                                                            float* __restrict__ dqkv) {
+  constexpr int TMAX = TAIL > 0 ? TAIL : 1;
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 32 * ATT_LD + 2 * 32];
   float* Ks = smem;
   float* Vs = smem + 2 * 32 * ATT_LD;
@@ -391,9 +395,9 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g,
   __shared__ __attribute__((aligned(16))) float vecQ[ATT_TAIL_MAX][ATT_HD], vecD[ATT_TAIL_MAX][ATT_HD];
   __shared__ float vred[W][ATT_TAIL_MAX][ATT_HD], tailSt[ATT_TAIL_MAX];
   const int nt = g.n - g.nm;
-  float vlse[ATT_TAIL_MAX], vD[ATT_TAIL_MAX], vdq[ATT_TAIL_MAX];
+  float vlse[TMAX], vD[TMAX], vdq[TMAX];
 #pragma unroll
-  for (int t = 0; t < ATT_TAIL_MAX; ++t) { vlse[t] = INFINITY; vD[t] = 0.f; vdq[t] = 0.f; }
+  for (int t = 0; t < TMAX; ++t) { vlse[t] = INFINITY; vD[t] = 0.f; vdq[t] = 0.f; }
   const size_t rs = (size_t)3 * g.H * ATT_HD, os = (size_t)g.H * ATT_HD;
   const float* Qb = g.qkv + qkv_off(g, b, 0, 0, h);
   const float* Kb = g.qkv + qkv_off(g, b, 0, 1, h);
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g,
   if (tid < nt) tailSt[tid] = key_state(g, b, g.nm + tid, g.n);
   if (vec)
 #pragma unroll
-    for (int t = 0; t < ATT_TAIL_MAX; ++t)
+    for (int t = 0; t < TMAX; ++t)
       if (t < nt) {
         const float dv = dOb[(size_t)(g.nm + t) * os + lane];
         if (wave == 0) {
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g,
       const float* vt = Vs + cur * 32 * ATT_LD;
       const bool att = Kst[cur * 32 + (lane & 31)] == 0.f;
 #pragma unroll
-      for (int t = 0; t < ATT_TAIL_MAX; ++t)
+      for (int t = 0; t < TMAX; ++t)
         if (t < nt) {
           const float sv = vec_row_dot(kt, vecQ[t], lane), dpv = vec_row_dot(vt, vecD[t], lane);
           const float pv = att ? fast_exp(sv * g.scale - vlse[t]) : 0.f;
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g,
   }
   if (vec) {        // remainder queries: wave 0 adds the remainder keys, the waves' partial dQ rows are summed, wave 0 writes
 #pragma unroll
-    for (int t = 0; t < ATT_TAIL_MAX; ++t)
+    for (int t = 0; t < TMAX; ++t)
       if (t < nt) {
         if (wave == 0)
           for (int j = g.nm; j < g.n; ++j) {
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g,
     __syncthreads();
     if (wave == 0)
 #pragma unroll
-      for (int t = 0; t < ATT_TAIL_MAX; ++t)
+      for (int t = 0; t < TMAX; ++t)
         if (t < nt) {
           float a = 0.f;
 #pragma unroll
@@ -531,6 +535,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dq_kernel(const AttGeom g,
 template <int W, int TAIL>
 __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dkv_kernel(const AttGeom g, const float* __restrict__ dO, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dvec, float* __restrict__ dqkv) {
+  constexpr int TMAX = TAIL > 0 ? TAIL : 1;
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * 32 * ATT_LD + 2 * 64];
   float* Qs = smem;
   float* dOs = smem + 2 * 32 * ATT_LD;
@@ -547,10 +552,10 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dkv_kernel(const AttGeom g
   __shared__ __attribute__((aligned(16))) float vecK[ATT_TAIL_MAX][ATT_HD], vecV[ATT_TAIL_MAX][ATT_HD];
   __shared__ float vred[W][ATT_TAIL_MAX][2][ATT_HD];
   const int nt = g.n - g.nm;
-  float vdk[ATT_TAIL_MAX], vdv[ATT_TAIL_MAX];
-  bool vatt[ATT_TAIL_MAX];
+  float vdk[TMAX], vdv[TMAX];
+  bool vatt[TMAX];
 #pragma unroll
-  for (int t = 0; t < ATT_TAIL_MAX; ++t) { vdk[t] = 0.f; vdv[t] = 0.f; vatt[t] = false; }
+  for (int t = 0; t < TMAX; ++t) { vdk[t] = 0.f; vdv[t] = 0.f; vatt[t] = false; }
   const size_t rs = (size_t)3 * g.H * ATT_HD, os = (size_t)g.H * ATT_HD;
   const float* Qb = g.qkv + qkv_off(g, b, 0, 0, h);
   const float* Kb = g.qkv + qkv_off(g, b, 0, 1, h);
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dkv_kernel(const AttGeom g
   own_rows_load(vreg, Vb, rs, vecwg ? g.nm : key, g.nm, half);
   if (vec)
 #pragma unroll
-    for (int t = 0; t < ATT_TAIL_MAX; ++t)
+    for (int t = 0; t < TMAX; ++t)
       if (t < nt) {
         if (wave == 0) {
           vecK[t][lane] = Kb[(size_t)(g.nm + t) * rs + lane];
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dkv_kernel(const AttGeom g
       const float* dt = dOs + cur * 32 * ATT_LD;
       const float lse_q = Rs[cur * 64 + (lane & 31)], d_q = Rs[cur * 64 + 32 + (lane & 31)];
 #pragma unroll
-      for (int t = 0; t < ATT_TAIL_MAX; ++t)
+      for (int t = 0; t < TMAX; ++t)
         if (t < nt) {
           const float sv = vec_row_dot(qt, vecK[t], lane), dpv = vec_row_dot(dt, vecV[t], lane);
           const float pv = vatt[t] ? fast_exp(sv * g.scale - lse_q) : 0.f;
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dkv_kernel(const AttGeom g
   }
   if (vec) {        // remainder keys: wave 0 adds the remainder queries, the waves' partial dK / dV rows are summed, wave 0 writes
 #pragma unroll
-    for (int t = 0; t < ATT_TAIL_MAX; ++t)
+    for (int t = 0; t < TMAX; ++t)
       if (t < nt) {
         if (wave == 0)
           for (int qq = g.nm; qq < g.n; ++qq) {
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(64 * W, 2) void attn_bwd_dkv_kernel(const AttGeom g
     __syncthreads();
     if (wave == 0)
 #pragma unroll
-      for (int t = 0; t < ATT_TAIL_MAX; ++t)
+      for (int t = 0; t < TMAX; ++t)
         if (t < nt) {
           float a = 0.f, c = 0.f;
 #pragma unroll
@@ -879,10 +884,14 @@ extern "C" int mla_attention_fwd(const float* qkv, const float* pad_mask, float*
   if (nm > 0) {
     const int W = att_waves(nm);
     const dim3 grid(cdiv(nm, 32 * W), B * H);
-    if (nm < n) {         // wave 0 of workgroup 0 also owns the remainder rows
+    if (nm + 1 == n) {    // wave 0 of workgroup 0 also owns the remainder rows; one row ([cls] + 256 patches): 3 instead of 9 state registers
       if (W == 4) attn_fwd_kernel<4, 1><<<grid, 256, 0, st>>>(g, o, lse);
       else if (W == 3) attn_fwd_kernel<3, 1><<<grid, 192, 0, st>>>(g, o, lse);
       else attn_fwd_kernel<2, 1><<<grid, 128, 0, st>>>(g, o, lse);
+    } else if (nm < n) {
+      if (W == 4) attn_fwd_kernel<4, ATT_TAIL_MAX><<<grid, 256, 0, st>>>(g, o, lse);
+      else if (W == 3) attn_fwd_kernel<3, ATT_TAIL_MAX><<<grid, 192, 0, st>>>(g, o, lse);
+      else attn_fwd_kernel<2, ATT_TAIL_MAX><<<grid, 128, 0, st>>>(g, o, lse);
     } else {
       if (W == 4) attn_fwd_kernel<4, 0><<<grid, 256, 0, st>>>(g, o, lse);
       else if (W == 3) attn_fwd_kernel<3, 0><<<grid, 192, 0, st>>>(g, o, lse);
@@ -906,7 +915,7 @@ extern "C" int mla_attention_bwd(const float* d_o, const float* qkv, const float
   const dim3 grid(cdiv(nm > 0 ? nm : 1, 32 * W), B * H), tail(B * H, n - nm);
   // order matters: the query-side kernel writes dvec (rowsum(d_o * o)) for every row before the key-side kernel reads it
   if (nm > 0) {
-    if (nm < n) {
+    if (nm + 1 == n) {
       if (W == 4) attn_bwd_dq_kernel<4, 1><<<grid, 256, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
       else if (W == 3) attn_bwd_dq_kernel<3, 1><<<grid, 192, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
       else attn_bwd_dq_kernel<2, 1><<<grid, 128, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
@@ -914,6 +923,14 @@ extern "C" int mla_attention_bwd(const float* d_o, const float* qkv, const float
       if (W == 4) attn_bwd_dkv_kernel<4, 1><<<grid, 256, 0, st>>>(g, d_o, lse, dvec, dqkv);
       else if (W == 3) attn_bwd_dkv_kernel<3, 1><<<grid, 192, 0, st>>>(g, d_o, lse, dvec, dqkv);
       else attn_bwd_dkv_kernel<2, 1><<<grid, 128, 0, st>>>(g, d_o, lse, dvec, dqkv);
+    } else if (nm < n) {
+      if (W == 4) attn_bwd_dq_kernel<4, ATT_TAIL_MAX><<<grid, 256, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
+      else if (W == 3) attn_bwd_dq_kernel<3, ATT_TAIL_MAX><<<grid, 192, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
+      else attn_bwd_dq_kernel<2, ATT_TAIL_MAX><<<grid, 128, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
+      MLA_CHECK_LAUNCH("attn_bwd_dq_kernel");
+      if (W == 4) attn_bwd_dkv_kernel<4, ATT_TAIL_MAX><<<grid, 256, 0, st>>>(g, d_o, lse, dvec, dqkv);
+      else if (W == 3) attn_bwd_dkv_kernel<3, ATT_TAIL_MAX><<<grid, 192, 0, st>>>(g, d_o, lse, dvec, dqkv);
+      else attn_bwd_dkv_kernel<2, ATT_TAIL_MAX><<<grid, 128, 0, st>>>(g, d_o, lse, dvec, dqkv);
     } else {
       if (W == 4) attn_bwd_dq_kernel<4, 0><<<grid, 256, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
       else if (W == 3) attn_bwd_dq_kernel<3, 0><<<grid, 192, 0, st>>>(g, d_o, o, lse, dvec, dqkv);
