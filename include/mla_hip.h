@@ -131,6 +131,24 @@ int mla_conv2d_wgrad_tr(int on);
  * input patch (conv_patch_split.hip) for the 3x3 / stride 1 / pad 1 forward and input-gradient launches whose grid fills the chip,
  * 2 = for all of them; other values: query.  Returns the setting. */
 int mla_conv2d_patch(int on);
+/* BatchNorm folded into the operands of the 64 -> 64 channel 3x3 / stride 1 / pad 1 convolutions (split arithmetic; conv2 of the layer1
+ * BasicBlocks, models/backbone.py:38-46: conv1 -> bn1 -> relu -> conv2).  The consumers of a = relu(bn1(y1)) -- conv2's forward, conv2's weight
+ * gradient and the ReLU mask of conv2's input gradient -- form it from y1 with the expression of mla_bn_apply, bit for bit, so `a` is
+ * never written or read.  in_* / mask_*: per-channel BatchNorm parameters (training: batch statistics; evaluation: running statistics).
+ * mla_conv2d_bnfold_supported: 1 where these entry points apply (they fail with MLA_ERR_INVALID_ARG elsewhere).
+ *   mla_conv2d_fwd_split_bnin     = mla_conv2d_fwd_split   over relu(bn(x))
+ *   mla_conv2d_wgrad_split_bnin   = mla_conv2d_wgrad_split over relu(bn(x))
+ *   mla_conv2d_dgrad_split_bnmask = mla_conv2d_dgrad_split_bn with relu_src := relu(bn(reqs[0].x)) (gamma / beta given; mean / invstd: the request's) */
+int mla_conv2d_bnfold_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int mla_conv2d_fwd_split_bnin(const float* x, const void* wsplit_t, float* y, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                              int stride, int pad, const float* in_mean, const float* in_invstd, const float* in_gamma, const float* in_beta,
+                              float* bn_partial, int* bn_tiles, void* stream);
+int mla_conv2d_wgrad_split_bnin(const float* x, const float* dy, float* dw_hwio, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                int stride, int pad, const float* in_mean, const float* in_invstd, const float* in_gamma,
+                                const float* in_beta, void* ws, size_t ws_bytes, void* stream);
+int mla_conv2d_dgrad_split_bnmask(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                  int stride, int pad, const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles, const float* mask_gamma,
+                                  const float* mask_beta, void* stream);
 /* measurement / test hook: 0 = one launch per output parity class of a stride-2 input gradient (split arithmetic), 1 (default;
  * $MLA_DGRAD_MERGE overrides) = all classes in one launch, longest K first; other values: query.  Returns the setting. */
 int mla_conv2d_dgrad_merge(int on);

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void bn_finalize_tiles_wide_kernel(const PT* _
 __device__ __forceinline__ f32x4 bn_val(const f32x4 x, const f32x4 mu, const f32x4 is, const f32x4 ga, const f32x4 be) {
   f32x4 r;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) r[e] = fmaf((x[e] - mu[e]) * is[e], ga[e], be[e]);
+  for (int e = 0; e < 4; ++e) r[e] = bn_val1(x[e], mu[e], is[e], ga[e], be[e]);
   return r;
 }
 

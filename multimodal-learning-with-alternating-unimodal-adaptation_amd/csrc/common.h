@@ -48,6 +48,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// the one BatchNorm expression (explicit fma) every kernel that forms or re-forms bn(x) uses: identical rounding everywhere
+// (bn.hip: bn_val; the convolution kernels that fold relu(bn(.)) into their operand staging)
+__device__ __forceinline__ float bn_val1(float x, float mu, float is, float ga, float be) { return fmaf((x - mu) * is, ga, be); }
+
 // Logical tile id -> (tm, tn).  Narrow outputs (gridN <= 8: every ResNet conv) keep the row-major order.  Wide outputs
 // (transformer Linears: N = 768..3072, up to 48 column tiles) are walked in column PANELS of 8 tiles: all row tiles of a
 // panel before the next panel, so the panel's B operand (8 x BN x K x 4 B <= 3 MB) stays in the 4 MB per-XCD L2 while A

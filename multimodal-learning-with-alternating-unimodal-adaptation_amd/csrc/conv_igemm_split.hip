@@ -601,6 +601,8 @@ static int pick_scfg(long M, int CO, int weight, int k_total = 1 << 30) {
 bool mla_patch_supported(const IGemmGeom& g, bool force);
 int mla_patch_launch(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part, const IGemmGeom& g,
                      int* bn_tiles, hipStream_t st);
+bool mla_patch64p_usable(const IGemmGeom& g);
+static int g_wgrad_tr = 1;                            // mla_conv2d_wgrad_tr: the all-taps weight-gradient kernels (wgrad_tr_split.hip)
 static int g_patch = -1;                              // -1: not yet read from $MLA_CONV_PATCH (default 1)
 static int patch_mode() {
   if (g_patch < 0) {
@@ -759,6 +761,49 @@ extern "C" int mla_conv2d_fwd_split(const float* x, const void* wsplit_t, float*
   return launch_split(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, cfg, (hipStream_t)stream, nullptr, nullptr, bn_tiles);
 }
 
+// ---- BatchNorm folded into the operands of the 64 -> 64 channel 3x3 / 1 / 1 convolutions (conv2 of the layer1 BasicBlocks,
+// models/backbone.py:38-46: conv1 -> bn1 -> relu -> conv2): relu(bn1(y1)) is formed by the consumers -- conv2's forward patch staging, conv2's
+// weight-gradient staging, the ReLU mask of conv2's input-gradient epilogue -- from y1 with bn_apply_kernel's expression (bit-identical to
+// the materialised path), so the activation tensor is never written (154 MB per block at batch 64) nor read.
+extern "C" int mla_conv2d_bnfold_supported(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+  if (!(Cin == 64 && Cout == 64 && KH == 3 && KW == 3 && stride == 1 && pad == 1) || N <= 0 || H <= 0 || W <= 0) return 0;
+  if (g_split_terms != 6 || g_split_cfg >= 0 || !patch_mode() || !g_wgrad_tr) return 0;
+  IGemmGeom g;
+  make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  // only where the persistent patch kernel is what the unfolded convolution would run on anyway (its grid fills the chip, or it is forced):
+  // folding then never changes which kernel -- and so which summation order -- a layer gets
+  return (use_patch(g) && mla_patch64p_usable(g)) ? 1 : 0;
+}
+
+extern "C" int mla_conv2d_fwd_split_bnin(const float* x, const void* wsplit_t, float* y, int N, int H, int W, int Cin, int Cout, int KH,
+                                         int KW, int stride, int pad, const float* in_mean, const float* in_invstd, const float* in_gamma,
+                                         const float* in_beta, float* bn_partial, int* bn_tiles, void* stream) {
+  if (int rc = check_conv("mla_conv2d_fwd_split_bnin", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
+  MLA_REQUIRE(x && wsplit_t && y && in_mean && in_invstd && in_gamma && in_beta, "mla_conv2d_fwd_split_bnin: null pointer");
+  MLA_REQUIRE(mla_conv2d_bnfold_supported(N, H, W, Cin, Cout, KH, KW, stride, pad), "mla_conv2d_fwd_split_bnin: unsupported (mla_conv2d_bnfold_supported)");
+  IGemmGeom g;
+  make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  g.in_bn[0] = in_mean; g.in_bn[1] = in_invstd; g.in_bn[2] = in_gamma; g.in_bn[3] = in_beta;
+  return mla_patch_launch(x, wsplit_t, y, nullptr, nullptr, bn_partial, g, bn_tiles, (hipStream_t)stream);
+}
+
+extern "C" int mla_conv2d_dgrad_split_bnmask(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout, int KH,
+                                             int KW, int stride, int pad, const mla_bn_reduce_req* reqs, int nreq, int* bn_tiles,
+                                             const float* mask_gamma, const float* mask_beta, void* stream) {
+  if (int rc = check_conv("mla_conv2d_dgrad_split_bnmask", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
+  MLA_REQUIRE(dy && wsplit && dx && reqs && nreq == 1 && mask_gamma && mask_beta, "mla_conv2d_dgrad_split_bnmask: one reduction request and the mask's gamma / beta are required");
+  MLA_REQUIRE(mla_conv2d_bnfold_supported(N, H, W, Cin, Cout, KH, KW, stride, pad), "mla_conv2d_dgrad_split_bnmask: unsupported (mla_conv2d_bnfold_supported)");
+  IGemmGeom g;
+  make_dgrad_geom(g, 0, 0, N, H, W, Cin, Cout, KH, KW, stride, pad);
+  int tiles = 0;
+  if (int rc = attach_bn_reqs("mla_conv2d_dgrad_split_bnmask", g, reqs, nreq, tiles)) return rc;
+  g.mask_gb[0] = mask_gamma; g.mask_gb[1] = mask_beta;
+  int ptiles = 0;
+  if (int rc = mla_patch_launch(dy, wsplit, dx, nullptr, nullptr, nullptr, g, &ptiles, (hipStream_t)stream)) return rc;
+  if (bn_tiles) *bn_tiles = ptiles;
+  return MLA_OK;
+}
+
 extern "C" int mla_conv2d_dgrad_split(const float* dy, const void* wsplit, float* dx, int N, int H, int W, int Cin, int Cout,
                                       int KH, int KW, int stride, int pad, const float* residual, const float* relu_src,
                                       void* stream) {
@@ -876,8 +921,7 @@ static void wgrad_split_plan(long M, int Cin, int Cout, int T, int* span, int* s
 bool mla_wgrad_tr_supported(int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 size_t mla_wgrad_tr_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
-                        hipStream_t st);
-static int g_wgrad_tr = 1;
+                        hipStream_t st, const float* const* in_bn);
 extern "C" int mla_conv2d_wgrad_tr(int on) {          // measurement hook: 0 = the per-tap kernel everywhere, 1 = default; other: query
   if (on == 0 || on == 1) g_wgrad_tr = on;
   return g_wgrad_tr;
@@ -902,7 +946,7 @@ extern "C" int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw
   MLA_REQUIRE(x && dy && dw && ws, "mla_conv2d_wgrad_split: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (g_wgrad_tr && mla_wgrad_tr_supported(W, Cin, Cout, KH, KW, stride, pad))
-    return mla_wgrad_tr_launch(x, dy, dw, N, H, W, Cin, Cout, ws, ws_bytes, st);
+    return mla_wgrad_tr_launch(x, dy, dw, N, H, W, Cin, Cout, ws, ws_bytes, st, nullptr);
   IGemmGeom g;
   make_fwd_geom(g, N, H, W, Cin, Cout, KH, KW, stride, pad);
   g.y_bytes = (unsigned)((size_t)g.M * Cout * 4);
@@ -923,6 +967,16 @@ extern "C" int mla_conv2d_wgrad_split(const float* x, const float* dy, float* dw
   }
   MLA_CHECK_LAUNCH("wgrad_split_kernel");
   return mla_wgrad_reduce(part, dw, (size_t)g.T * Cin * Cout / 4, splits, st);
+}
+
+extern "C" int mla_conv2d_wgrad_split_bnin(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                           int stride, int pad, const float* in_mean, const float* in_invstd, const float* in_gamma,
+                                           const float* in_beta, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_conv("mla_conv2d_wgrad_split_bnin", N, H, W, Cin, Cout, KH, KW, stride, pad)) return rc;
+  MLA_REQUIRE(x && dy && dw && ws && in_mean && in_invstd && in_gamma && in_beta, "mla_conv2d_wgrad_split_bnin: null pointer");
+  MLA_REQUIRE(mla_conv2d_bnfold_supported(N, H, W, Cin, Cout, KH, KW, stride, pad), "mla_conv2d_wgrad_split_bnin: unsupported (mla_conv2d_bnfold_supported)");
+  const float* in_bn[4] = {in_mean, in_invstd, in_gamma, in_beta};
+  return mla_wgrad_tr_launch(x, dy, dw, N, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, in_bn);
 }
 
 // ---------------------------------------------------------------------------------------------

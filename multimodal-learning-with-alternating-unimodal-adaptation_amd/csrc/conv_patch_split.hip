@@ -233,14 +233,20 @@ __global__ __launch_bounds__(512, 2) void patch_split_kernel(const float* __rest
 // lane for the whole launch and reduced once at the end: one partial row per workgroup (no barrier inside the epilogue).
 // Cin = Cout = 64 only: 2 chunks x 5 two-tap stages = 10 unrolled stages per tile.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool HAS_R, bool HAS_MASK, int NREQ, bool STATS>
+// BNIN (forward): the gathered tensor is a convolution output y and the operand is relu(bn(y)) -- BatchNorm + ReLU applied to every loaded
+// value on its way into the patch planes (padding stays zero), so the activation tensor between conv1 and conv2 of a BasicBlock is never
+// written or read.  BNMASK (input gradient): the ReLU mask of that activation is re-formed from the BatchNorm input the epilogue reads
+// anyway for the fused reduction (bn_x[0]) instead of loading the activation.  Both use bn_val1, the expression of bn_apply_kernel.
+template <bool HAS_R, bool HAS_MASK, int NREQ, bool STATS, bool BNIN = false, bool BNMASK = false>
 __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__ X, const void* __restrict__ Wsp, float* Y,
                                                            const float* R, const float* MASK, double* __restrict__ part,
                                                            const IGemmGeom g, int ntiles) {
   constexpr int BN = 64, WN = 2, MI = 2, TPS = 2, SPC = 5, NC = 2, NSTG = NC * SPC;
   constexpr int BSLOT = 3 * 128 * 16;
+  static_assert(!BNMASK || (NREQ >= 1 && !HAS_MASK), "the mask is re-formed from the first reduction request's BatchNorm input");
   __shared__ __attribute__((aligned(16))) unsigned P[3 * PT_PPL];
   __shared__ __attribute__((aligned(16))) unsigned Bs[2 * BSLOT];
+  __shared__ __attribute__((aligned(16))) float bnt[BNIN ? 4 : 1][64];       // BNIN: {mean, invstd, gamma, beta} of the 64 input channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -248,6 +254,9 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
   const int gH = g.H, gW = g.W;
   const int prow = gW + 2;
   const int col = wn * 32 + i;                                  // this lane's output column
+  if constexpr (BNIN) {
+    if (tid < 256) bnt[tid >> 6][tid & 63] = g.in_bn[tid >> 6][tid & 63];        // (read after the first barrier)
+  }
   const unsigned plane_bytes = g.w_bytes / 2;
   const unsigned t_bytes = (unsigned)g.M * 64u * 4u;           // every (M, 64) fp32 tensor of this launch
   const rsrc_t xr = make_rsrc(X, g.x_bytes), wr = make_rsrc(Wsp, 3 * plane_bytes), yr = make_rsrc(Y, t_bytes);
@@ -258,6 +267,7 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
 
   // ---- patch staging of (tile, chunk)
   f32x4 pre[PT_NPRE];
+  unsigned pre_ok = 0;                           // BNIN: which of the eight staged slots hold real pixels (padding must stay 0 after BatchNorm)
   const unsigned prow_inv = (65536u + (unsigned)prow - 1u) / (unsigned)prow;      // pp / prow == (pp * prow_inv) >> 16 for pp < 512, prow < 64
   auto patch_load = [&](int tile, int c0) {
     const int m0 = tile * PT_BM;
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
     const int npx = tile < ntiles ? (mlast / gW - r0 + 3) * prow : 0;
     int zero = 0;
     asm volatile("" : "+v"(zero));               // (keeps the eight slot addresses from being hoisted out of the tile loop: 30 VGPRs)
+    unsigned okbits = 0;
 #pragma unroll
     for (int u = 0; u < PT_NPRE; ++u) {
       const int s = tid + 512 * u + zero, pp = s >> 3, c4 = s & 7;
@@ -274,12 +285,28 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
       const int ok = (int)(pp < npx) & (int)((unsigned)gr < (unsigned)(g.N * gH)) & (int)((unsigned)x < (unsigned)gW);
       const unsigned off = ((unsigned)(gr * gW + x) * 64u + (unsigned)(c0 + 4 * c4)) * 4u;
       pre[u] = buf_load4(xr, off | ((unsigned)ok - 1u), 0);
+      okbits |= (unsigned)ok << u;
     }
+    if constexpr (BNIN) pre_ok = okbits;
   };
-  auto patch_store = [&]() {
+  auto patch_store = [&](int c0) {               // c0: the channel chunk the staged registers hold (BNIN: selects the BatchNorm parameters)
+    f32x4 bmu_, bis_, bga_, bbe_;
+    if constexpr (BNIN) {
+      const int c = c0 + 4 * (tid & 7);          // slot s = tid + 512 u: the thread's four channels are the same in every pass
+      bmu_ = *reinterpret_cast<const f32x4*>(&bnt[0][c]);
+      bis_ = *reinterpret_cast<const f32x4*>(&bnt[1][c]);
+      bga_ = *reinterpret_cast<const f32x4*>(&bnt[2][c]);
+      bbe_ = *reinterpret_cast<const f32x4*>(&bnt[3][c]);
+    }
 #pragma unroll
     for (int u = 0; u < PT_NPRE; ++u) {
       const int s = tid + 512 * u, pp = s >> 3, c4 = s & 7;
+      if constexpr (BNIN) {
+        const unsigned okm = 0u - ((pre_ok >> u) & 1u);          // all ones / zero: branch-free
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pre[u][e] = __uint_as_float(__float_as_uint(fmaxf(bn_val1(pre[u][e], bmu_[e], bis_[e], bga_[e], bbe_[e]), 0.f)) & okm);
+      }
       unsigned h0, m0_, l0, h1, m1, l1;
       split_pair<true>(pre[u][0], pre[u][1], h0, m0_, l0);
       split_pair<true>(pre[u][2], pre[u][3], h1, m1, l1);
@@ -333,6 +360,8 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
   double csum = 0.0, csq = 0.0;                                 // STATS: forward BatchNorm statistics of this lane's column
   float rb0 = 0.f, rb1[2] = {0.f, 0.f};                         // NREQ: sum v, sum v * xhat_q over every tile of this workgroup
   float bmu[2] = {0.f, 0.f}, bis[2] = {0.f, 0.f};
+  float mga = 0.f, mbe = 0.f;
+  if constexpr (BNMASK) { mga = g.mask_gb[0][col]; mbe = g.mask_gb[1][col]; }
   if constexpr (NREQ > 0) { bmu[0] = g.bn_mean[0][col]; bis[0] = g.bn_invstd[0][col]; }
   if constexpr (NREQ > 1) { bmu[1] = g.bn_mean[1][col]; bis[1] = g.bn_invstd[1][col]; }
   struct Piece { float r[4], mk[4], bx[2][4]; };
@@ -357,6 +386,7 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
       float v = prev[mi][4 * eq + e4];
       if constexpr (HAS_R) v += pc.r[e4];
       if constexpr (HAS_MASK) v = pc.mk[e4] > 0.f ? v : 0.f;
+      if constexpr (BNMASK) v = fmaxf(bn_val1(pc.bx[0][e4], bmu[0], bis[0], mga, mbe), 0.f) > 0.f ? v : 0.f;     // relu(bn(y)) > 0, as bn_apply formed it
       buf_store1i(yr, v, off, e4 * 256);
       if constexpr (STATS) {                                      // fp64 as in igemm_epilogue (rows past M are exact zeros); rides in the MFMA shadow
         const double vd = (double)v;
@@ -374,8 +404,8 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
   int tile = blockIdx.x;
   patch_load(tile, 0);
   b_load(0, 0);
-  __syncthreads();                               // the zero pixel is written
-  patch_store();
+  __syncthreads();                               // the zero pixel (and the BatchNorm table) is written
+  patch_store(0);
   b_store(0);
   __syncthreads();
   Frags f0;
@@ -437,7 +467,7 @@ __global__ __launch_bounds__(512) void patch64p_kernel(const float* __restrict__
       }
       if (st == SPC - 1) {                       // chunk boundary: every wave is done with this patch
         __syncthreads();
-        patch_store();
+        patch_store(c == 0 ? 32 : 0);            // this tile's second chunk / the next tile's first
       }
       __syncthreads();
     }
@@ -521,6 +551,12 @@ static bool patch_persistent_on() {
   return g_patch_persistent != 0;
 }
 
+// does the persistent 64 -> 64 kernel (and with it the folded-BatchNorm variants) serve this geometry?
+bool mla_patch64p_usable(const IGemmGeom& g) {
+  return g.C == 64 && g.CO == 64 && patch_persistent_on() && (long)g.M * 64 * 4 < 0xFFFFFFF0L && cdiv(g.M, PT_BM) >= 2 &&
+         mla_patch_supported(g, true);
+}
+
 int mla_patch_launch(const float* X, const void* Wsp, float* Y, const float* R, const float* MASK, float* part, const IGemmGeom& g,
                      int* bn_tiles, hipStream_t st) {
   const int BN = g.CO % 128 == 0 ? 128 : 64;
@@ -535,7 +571,15 @@ int mla_patch_launch(const float* X, const void* Wsp, float* Y, const float* R, 
     double* pd = reinterpret_cast<double*>(part);
     bool done = true;
 #define P64(R_, M_, N_, S_) patch64p_kernel<R_, M_, N_, S_><<<grid, 512, 0, st>>>(X, Wsp, Y, R, MASK, pd, g, tiles)
-    if (!R && !MASK && nreq == 0 && part) P64(false, false, 0, true);            // forward, training
+    if (g.in_bn[0]) {                                                            // forward over relu(bn(x))
+      if (!R && !MASK && nreq == 0 && part) patch64p_kernel<false, false, 0, true, true, false><<<grid, 512, 0, st>>>(X, Wsp, Y, R, MASK, pd, g, tiles);
+      else if (!R && !MASK && nreq == 0) patch64p_kernel<false, false, 0, false, true, false><<<grid, 512, 0, st>>>(X, Wsp, Y, R, MASK, pd, g, tiles);
+      else done = false;
+    } else if (g.mask_gb[0]) {                                                   // input gradient, ReLU mask from the BatchNorm input of request 0
+      if (!R && !MASK && nreq == 1 && !part) patch64p_kernel<false, false, 1, false, false, true><<<grid, 512, 0, st>>>(X, Wsp, Y, R, MASK, pd, g, tiles);
+      else done = false;
+    }
+    else if (!R && !MASK && nreq == 0 && part) P64(false, false, 0, true);       // forward, training
     else if (!R && !MASK && nreq == 0) P64(false, false, 0, false);              // forward, evaluation
     else if (!R && MASK && nreq == 1 && !part) P64(false, true, 1, false);       // conv2 input gradient
     else if (R && MASK && nreq == 1 && !part) P64(true, true, 1, false);         // conv1 input gradient, block below without downsample
@@ -549,6 +593,10 @@ int mla_patch_launch(const float* X, const void* Wsp, float* Y, const float* R, 
       if (bn_tiles) *bn_tiles = grid;
       return MLA_OK;
     }
+  }
+  if (g.in_bn[0] || g.mask_gb[0]) {           // folded BatchNorm exists in the persistent 64 -> 64 kernel only: never drop it silently
+    mla_set_error("mla_conv2d_*_bn{in,mask}: unsupported shape / operand combination (see mla_conv2d_bnfold_supported)");
+    return MLA_ERR_INVALID_ARG;
   }
   if (bn_tiles) *bn_tiles = tiles;
   if (BN == 128) patch_split_kernel<128><<<total, 512, 0, st>>>(X, Wsp, Y, R, MASK, part, g);

@@ -29,7 +29,12 @@ struct IGemmGeom {
   float* bn_part[2];
   int bn_tile0;
   int m0;                  // first output row of this launch (split kernels: a launch may cover the row window [m0, M) of the problem)
+  // BatchNorm folded into this launch's operands (the 64 -> 64 persistent patch kernel; conv1 -> bn1 -> relu -> conv2 of a BasicBlock,
+  // models/backbone.py:38-46, without materialising relu(bn1(.))):
+  const float* in_bn[4];   // forward: the gathered tensor is y and the convolution runs over relu(bn(y)); {mean, invstd, gamma, beta} per channel
+  const float* mask_gb[2]; // input gradient: the ReLU mask is bn(bn_x[0]) > 0 with {gamma, beta} (mean / invstd: bn_mean[0] / bn_invstd[0])
 };
+
 
 // Gathers use raw buffer loads: the hardware range check of the buffer descriptor returns 0 for any
 // offset >= num_records, so padding / out-of-range rows are "loaded" as zeros by pointing them at

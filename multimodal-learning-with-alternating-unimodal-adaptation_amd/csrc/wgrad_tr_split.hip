@@ -35,6 +35,7 @@ constexpr int WT_RACC = 9 * 64 * 64;                     // floats of one slab
 struct WtGeom {
   int N, H, W, tilesY, tilesX, ntiles;
   unsigned x_bytes;
+  const float* in_bn[4];     // BNIN: x is a convolution output y, the operand is relu(bn(y)): {mean, invstd, gamma, beta} per channel
 };
 
 __device__ __forceinline__ unsigned wt_off_or_oob(int ok, unsigned off) { return off | ((unsigned)ok - 1u); }
@@ -43,9 +44,11 @@ __device__ __forceinline__ s16x4 lds_tr(const unsigned* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
 }
 
+template <bool BNIN>
 __global__ __launch_bounds__(512, 2) void wgrad_tr_split_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                                  float* __restrict__ slabs, const WtGeom g) {
   __shared__ __attribute__((aligned(16))) unsigned S[(2 * WT_BUF + 64 > WT_RACC ? 2 * WT_BUF + 64 : WT_RACC)];
+  __shared__ __attribute__((aligned(16))) float bnt[BNIN ? 4 : 1][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sg = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;     // step group, ci block, co block
   const int i = lane & 31, h = lane >> 5;
@@ -62,9 +65,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_tr_split_kernel(const float* __r
   // ---- staging: pass u < WT_XU covers float4 slot tid + 512 u of the input patch (pixel = slot >> 4, 4 channels = slot & 15;
   // slots past 1600 are masked), pass u >= WT_XU slot tid + 512 (u - WT_XU) of the dy tile
   f32x4 pre[WT_NLD];
+  unsigned pre_ok = 0;                             // BNIN: which input-patch slots hold real pixels (image borders must stay 0 after BatchNorm)
+  if constexpr (BNIN) {
+    if (tid < 256) bnt[tid >> 6][tid & 63] = g.in_bn[tid >> 6][tid & 63];
+  }
   auto stage_load = [&](int t) {
     int n, oy0, ox0;
     decode(t, n, oy0, ox0);
+    unsigned okbits = 0;
 #pragma unroll
     for (int u = 0; u < WT_NLD; ++u) {
       const bool isx = u < WT_XU;                                                // compile-time
@@ -76,14 +84,29 @@ __global__ __launch_bounds__(512, 2) void wgrad_tr_split_kernel(const float* __r
       const int ok = (int)(px < (isx ? WT_SPX : WT_TPX)) & (int)((unsigned)iy < (unsigned)g.H) & (int)((unsigned)ix < (unsigned)g.W);
       const unsigned off = ((unsigned)((n * g.H + iy) * g.W + ix) * 64u + (unsigned)c4 * 4u) * 4u;
       pre[u] = buf_load4(isx ? xr : yr, wt_off_or_oob(ok, off), 0);
+      okbits |= (unsigned)ok << u;
     }
+    if constexpr (BNIN) pre_ok = okbits;
   };
+  int pz = 0;                                      // an opaque 0, renewed per tile in the BNIN variant (see wgrad_flat_tr_kernel): the LDS store
+                                                   // addresses of the six passes are then recomputed instead of living in ~12 hoisted registers
   auto stage_store = [&](int buf, int u) {
     const bool isx = u < WT_XU;
-    const int sl = tid + 512 * (isx ? u : u - WT_XU);
+    const int sl = tid + pz + 512 * (isx ? u : u - WT_XU);
     const int c4 = sl & 15;
     int px = sl >> 4;
     if (isx && px >= WT_SPX) px = WT_SPX - 1 + 0 * px;                          // masked slots (zeros) land on ... see below
+    if constexpr (BNIN) {
+      if (isx) {                                   // relu(bn(y)) of the thread's four channels (c4 = tid & 15 in every pass), bn_apply's expression
+        const int c = 4 * c4;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(&bnt[0][c]), is = *reinterpret_cast<const f32x4*>(&bnt[1][c]);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(&bnt[2][c]), be = *reinterpret_cast<const f32x4*>(&bnt[3][c]);
+        const unsigned okm = 0u - ((pre_ok >> u) & 1u);          // all ones / zero: branch-free (a select makes the compiler skip the block by exec mask)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pre[u][e] = __uint_as_float(__float_as_uint(fmaxf(bn_val1(pre[u][e], mu[e], is[e], ga[e], be[e]), 0.f)) & okm);
+      }
+    }
     unsigned h0, m0, l0, h1, m1, l1;
     split_pair<true>(pre[u][0], pre[u][1], h0, m0, l0);
     split_pair<true>(pre[u][2], pre[u][3], h1, m1, l1);
@@ -150,6 +173,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_tr_split_kernel(const float* __r
   constexpr int U = 2 * 9;                             // units of a tile for one wave: (step s, tap)
   for (; t < g.ntiles; t += gridDim.x) {
     const int tn = t + gridDim.x;
+    if constexpr (BNIN) asm volatile("" : "+v"(pz));
     if (tn < g.ntiles) stage_load(tn);                 // in flight while this tile computes
     const unsigned* Sc = S + cur * WT_BUF;
     Fr a0, a1, b0, b1;
@@ -160,9 +184,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_tr_split_kernel(const float* __r
       const int s = u / 9, t9 = u - s * 9;
       Fr& ac = (u & 1) ? a1 : a0;
       Fr& an = (u & 1) ? a0 : a1;
-      Fr& bc = s ? b1 : b0;
+      Fr& bc = (s && !BNIN) ? b1 : b0;
+      if (BNIN && u == 9) read_b(Sc, 1, b0);           // (BNIN: one dy fragment set -- the BatchNorm temporaries take its 12 registers --, one exposed LDS latency per tile)
       if (u + 1 < U) read_a(Sc, (u + 1) / 9, (u + 1) % 9, an);
-      if (u == 4) read_b(Sc, 1, b1);                   // the second step's dy fragments, well ahead
+      if (!BNIN && u == 4) read_b(Sc, 1, b1);          // the second step's dy fragments, well ahead
       if (u >= U - WT_NLD) stage_store(cur ^ 1, u - (U - WT_NLD));   // unconditional (stale registers without a next tile: never read)
 #pragma unroll
       for (int term = 0; term < 6; ++term)
@@ -606,7 +631,7 @@ size_t mla_wgrad_tr_ws_bytes(int N, int H, int W, int Cin, int Cout) {
 }
 
 int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
-                        hipStream_t st) {
+                        hipStream_t st, const float* const* in_bn) {
   const size_t need = mla_wgrad_tr_ws_bytes(N, H, W, Cin, Cout);
   if (ws_bytes < need) {
     mla_set_error("mla_conv2d_wgrad_split: workspace %zu < %zu bytes", ws_bytes, need);
@@ -620,11 +645,14 @@ int mla_wgrad_tr_launch(const float* x, const float* dy, float* dw, int N, int H
     g.tilesY = cdiv(H, WT_TH); g.tilesX = cdiv(W, WT_TW);
     g.ntiles = N * g.tilesY * g.tilesX;
     g.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
+    for (int k = 0; k < 4; ++k) g.in_bn[k] = in_bn ? in_bn[k] : nullptr;
     const int grid = g.ntiles < wt_cus() ? g.ntiles : wt_cus();
-    wgrad_tr_split_kernel<<<grid, 512, 0, st>>>(x, dy, (float*)ws, g);
+    if (in_bn) wgrad_tr_split_kernel<true><<<grid, 512, 0, st>>>(x, dy, (float*)ws, g);
+    else wgrad_tr_split_kernel<false><<<grid, 512, 0, st>>>(x, dy, (float*)ws, g);
     MLA_CHECK_LAUNCH("wgrad_tr_split_kernel");
     return mla_wgrad_reduce((const float*)ws, dw, (size_t)WT_RACC / 4, grid, st);
   }
+  MLA_REQUIRE(!in_bn, "mla_conv2d_wgrad_split_bnin: folded BatchNorm exists for the 64 -> 64 channel convolutions only");
   WfGeom g;
   g.M = N * H * W; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
   g.ntiles = cdiv(g.M, 64);

@@ -49,6 +49,10 @@ PROTOTYPES = {
     "mla_conv2d_patch": (_I, [_I]),
     "mla_conv2d_dgrad_merge": (_I, [_I]),
     "mla_conv2d_two_phase": (_I, [_I]),
+    "mla_conv2d_bnfold_supported": (_I, [_I] * 9),
+    "mla_conv2d_fwd_split_bnin": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P, _P, _P, _P]),
+    "mla_conv2d_wgrad_split_bnin": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _P, _P, _P, _P, _Z, _P]),
+    "mla_conv2d_dgrad_split_bnmask": (_I, [_P, _P, _P] + [_I] * 9 + [_P, _I, _P, _P, _P, _P]),
     "mla_conv2d_split_terms": (_I, [_I]),
     "mla_conv2d_stem_supported": (_I, [_I] * 6),
     "mla_conv2d_stem_waves": (_I, [_I]),

@@ -38,6 +38,10 @@ DEFAULT_CONV_MATH = "split"
 FUSE_BN_REDUCE = os.environ.get("MLA_FUSE_BN_REDUCE", "1") != "0"
 # measurement switch: 0 = the downsample input gradient is its own four-launch pass over dx (round 2)
 DS_DGRAD_FOLD = os.environ.get("MLA_DS_DGRAD_FOLD", "1") != "0"
+# conv1 -> bn1 -> relu -> conv2 of a BasicBlock (backbone.py:38-46) without materialising relu(bn1(.)): the three consumers of that
+# activation re-form it from conv1's output (bit-identical: ops.conv2d_*_bnin / _bnmask), where the kernels support it (the 64-channel
+# blocks of layer1 on the split arithmetic).  MLA_BN_FOLD=0 restores the bn_apply pass.
+BN_FOLD = os.environ.get("MLA_BN_FOLD", "1") != "0"
 
 
 def conv_specs(modality: str) -> List[Tuple[str, int, int, int, int, int]]:
@@ -261,6 +265,7 @@ class ResNet18Encoder(FlatModule):
                        "ds": has_ds}
                 for nm in ("y1", "a1", "y2", "out"):
                     blk[nm] = torch.empty((N, oh, ow, planes), **f32)
+                blk["fold"] = BN_FOLD and self.conv_math == "split" and ops.conv2d_bnfold_supported(N, oh, ow, planes, planes, 3, 3, 1, 1)
                 if has_ds:
                     blk["yd"] = torch.empty((N, oh, ow, planes), **f32)
                 blocks.append(blk)
@@ -322,8 +327,17 @@ class ResNet18Encoder(FlatModule):
             ops.bn_invstd(self.running[self._tot_bn:], self._rinv_flat)       # one launch for all 20 BN layers
         return self
 
-    def _conv_bn(self, ws, st, x, conv_name, stride, pad, y, out, relu, residual=None):
-        """y = conv(x); BN statistics fused in the conv epilogue; out = [relu](bn(y) [+ residual])."""
+    def _fold(self, blk) -> bool:
+        """True when relu(bn1(y1)) of this block is never materialised (training mode; see BN_FOLD)."""
+        return bool(self.training and blk.get("fold") and FUSE_BN_REDUCE)      # (the fold rides on the fused reduction's read of y1)
+
+    def _bn_in(self, ws, bn):
+        mean, invstd = ws["stats"][bn]
+        return (mean, invstd, self.p[bn + ".weight"], self.p[bn + ".bias"])
+
+    def _conv_bn(self, ws, st, x, conv_name, stride, pad, y, out, relu, residual=None, bn_in=None):
+        """y = conv(x); BN statistics fused in the conv epilogue; out = [relu](bn(y) [+ residual]).  out = None: the consumers of the
+        activation re-form it from y (BN_FOLD); bn_in: x is itself such a BatchNorm input and the convolution runs over relu(bn_in(x))."""
         w = self.p[conv_name + ".weight"]
         bn = bn_name_for_conv(conv_name)
         wsp = self.wsp.get(conv_name)
@@ -336,7 +350,9 @@ class ResNet18Encoder(FlatModule):
             ops.bn_apply(y, self.rm[bn], self.rinv[bn], self.p[bn + ".weight"], self.p[bn + ".bias"], out, y.numel() // C, C,
                          relu, residual=residual, stream=st)
             return
-        if wsp is not None:
+        if bn_in is not None:
+            _, tiles = ops.conv2d_fwd_split_bnin(x, wsp[0], w.shape, stride, pad, bn_in, y=y, bn_partial=ws["partial"], stream=st)
+        elif wsp is not None:
             _, tiles = ops.conv2d_fwd_split(x, wsp[0], w.shape, stride, pad, y=y, bn_partial=ws["partial"], stream=st)
         else:
             _, tiles = ops.conv2d_fwd(x, w, stride, pad, y=y, bn_partial=ws["partial"], stream=st)
@@ -345,6 +361,8 @@ class ResNet18Encoder(FlatModule):
         mean, invstd = ws["stats"][bn]
         ops.bn_finalize(ws["partial"], tiles, M, C, mean, invstd, self.rm[bn], self.rv[bn], stream=st)
         self.num_batches_tracked[bn] += 1
+        if out is None:
+            return
         ops.bn_apply(y, mean, invstd, self.p[bn + ".weight"], self.p[bn + ".bias"], out, M, C, relu, residual=residual,
                      stream=st)
 
@@ -383,6 +401,22 @@ class ResNet18Encoder(FlatModule):
         ops.bn_apply(y, mean, invstd, ga, be, out, y.numel() // 64, 64, True)
         return out
 
+    def block_a1(self, blk: dict, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """relu(bn1(conv1 output)) of a BasicBlock of the live forward (tests / inspection).  Blocks whose consumers re-form it from
+        conv1's output (BN_FOLD) never store it: rebuilt here by bn_apply -- the same expression, bit for bit.  gamma / beta: bn1's
+        affine parameters AT THE TIME OF THAT FORWARD if an optimizer step has changed them since."""
+        if not self._fold(blk):
+            return blk["a1"]
+        bn = blk["pre"] + ".bn1"
+        y = blk["y1"]
+        C = y.shape[3]
+        mean, invstd = self._ws["stats"][bn]
+        ga = self.p[bn + ".weight"] if gamma is None else gamma.to(y.device, torch.float32).contiguous()
+        be = self.p[bn + ".bias"] if beta is None else beta.to(y.device, torch.float32).contiguous()
+        out = torch.empty_like(y)
+        ops.bn_apply(y, mean, invstd, ga, be, out, y.numel() // C, C, True)
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,1,H,W) audio or (B,3,T,H,W) visual, fp32, reference layout.  Returns the NHWC feature
         map (N,h,w,512) of layer4 (backbone.py:142-160); activations are kept for backward()."""
@@ -417,14 +451,16 @@ class ResNet18Encoder(FlatModule):
         cur = ws["p0"]
         for blk in ws["blocks"]:                                                                 # :154-157
             pre = blk["pre"]
-            self._conv_bn(ws, st, cur, pre + ".conv1", blk["stride"], 1, blk["y1"], blk["a1"], relu=True)
+            fold = self._fold(blk)
+            self._conv_bn(ws, st, cur, pre + ".conv1", blk["stride"], 1, blk["y1"], None if fold else blk["a1"], relu=True)
             if blk["ds"]:
                 idn = ws["idn"][:blk["yd"].numel()].view(blk["yd"].shape)
                 self._conv_bn(ws, st, cur, pre + ".downsample.0", blk["stride"], 0, blk["yd"], idn, relu=False)
             else:
                 idn = cur
             # out = relu(bn2(conv2(a1)) + identity)   (backbone.py:43-50)
-            self._conv_bn(ws, st, blk["a1"], pre + ".conv2", 1, 1, blk["y2"], blk["out"], relu=True, residual=idn)
+            self._conv_bn(ws, st, blk["y1"] if fold else blk["a1"], pre + ".conv2", 1, 1, blk["y2"], blk["out"], relu=True, residual=idn,
+                          bn_in=self._bn_in(ws, pre + ".bn1") if fold else None)
             blk["xin"] = cur
             cur = blk["out"]
         self.grad_ready = False
@@ -458,12 +494,16 @@ class ResNet18Encoder(FlatModule):
         ops.avgpool_bwd(dfeat.contiguous(), d, NB, P, out.shape[3], relu_src=out, stream=st)
         self._backward_trunk(ws, st)
 
-    def _wgrad(self, ws, x, dy, name, stride, pad) -> None:
-        """Weight gradient of conv `name`; on the side stream when one is attached (after dy has been produced)."""
+    def _wgrad(self, ws, x, dy, name, stride, pad, bn_in=None) -> None:
+        """Weight gradient of conv `name`; on the side stream when one is attached (after dy has been produced).  bn_in: x is a BatchNorm
+        input and the operand is relu(bn_in(x)) (BN_FOLD)."""
         side = self.wgrad_stream
         wgrad = ops.conv2d_wgrad_split if name in self.wsp else ops.conv2d_wgrad
         if name == "conv1" and self.stem_split:
             wgrad = ops.conv2d_stem_wgrad_split
+        if bn_in is not None:
+            def wgrad(x_, dy_, dw_, stride_, pad_, ws_):                      # noqa: F811
+                return ops.conv2d_wgrad_split_bnin(x_, dy_, dw_, stride_, pad_, ws_, bn_in)
         if side is None:
             wgrad(x, dy, self.g[name + ".weight"], stride, pad, ws["wgrad_ws"])
             return
@@ -509,10 +549,17 @@ class ResNet18Encoder(FlatModule):
             d = G[0][:n_out].view(oshape)
             dy2 = DY[pre + ".conv2"]
             self._bn_bwd(ws, st, pre + ".bn2", d, blk["y2"], dy2, have.pop(pre + ".bn2", None))
-            self._wgrad(ws, blk["a1"], dy2, pre + ".conv2", 1, 1)
             da1 = G[2][:n_out].view(oshape)
-            got = self._dgrad(ws, st, dy2, pre + ".conv2", oshape, 1, 1, da1, relu_src=blk["a1"],
-                              bn_next=[(pre + ".bn1", blk["y1"], bnp[2])])
+            if self._fold(blk):
+                bn_in = self._bn_in(ws, pre + ".bn1")
+                self._wgrad(ws, blk["y1"], dy2, pre + ".conv2", 1, 1, bn_in=bn_in)
+                _, rt = ops.conv2d_dgrad_split_bnmask(dy2, self.wsp[pre + ".conv2"][1], self.p[pre + ".conv2.weight"].shape, oshape, 1, 1, da1,
+                                                      (blk["y1"],) + tuple(ws["stats"][pre + ".bn1"]) + (bnp[2],), bn_in[2], bn_in[3], stream=st)
+                got = {pre + ".bn1": (bnp[2], rt)}
+            else:
+                self._wgrad(ws, blk["a1"], dy2, pre + ".conv2", 1, 1)
+                got = self._dgrad(ws, st, dy2, pre + ".conv2", oshape, 1, 1, da1, relu_src=blk["a1"],
+                                  bn_next=[(pre + ".bn1", blk["y1"], bnp[2])])
             dy1 = DY[pre + ".conv1"]
             self._bn_bwd(ws, st, pre + ".bn1", da1, blk["y1"], dy1, got.get(pre + ".bn1"))
             self._wgrad(ws, xin, dy1, pre + ".conv1", blk["stride"], 1)

@@ -246,6 +246,61 @@ def conv2d_dgrad_split(dy: torch.Tensor, wsplit: torch.Tensor, w_shape, x_shape,
     return (dx, tiles.value) if nreq else dx
 
 
+def conv2d_bnfold_supported(N: int, H: int, W: int, Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int) -> bool:
+    """True where relu(bn(.)) can be folded into the operands of a convolution (64 -> 64 channels, 3x3 / 1 / 1, split arithmetic)."""
+    return bool(_lib.load().mla_conv2d_bnfold_supported(N, H, W, Cin, Cout, KH, KW, stride, pad))
+
+
+def conv2d_fwd_split_bnin(x: torch.Tensor, wsplit_t: torch.Tensor, w_shape, stride: int, pad: int, bn_in, y: Optional[torch.Tensor] = None,
+                          bn_partial: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> Tuple[torch.Tensor, int]:
+    """conv2d_fwd_split over relu(bn(x)); bn_in = (mean, invstd, gamma, beta) per input channel.  x is the BatchNorm's input."""
+    N, H, W, Cin = x.shape
+    KH, KW, Cin2, Cout = w_shape
+    if Cin2 != Cin:
+        raise MLAHipError(f"conv2d_fwd_split_bnin: x has {Cin} channels, weight expects {Cin2}")
+    if y is None:
+        y = torch.empty((N, conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad), Cout), device=x.device, dtype=torch.float32)
+    tiles = ctypes.c_int(0)
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_fwd_split_bnin(_p(x), _p(wsplit_t, torch.int16), _p(y), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                _p(bn_in[0]), _p(bn_in[1]), _p(bn_in[2]), _p(bn_in[3]), _p(bn_partial),
+                                                ctypes.addressof(tiles), stream or cur_stream()), "mla_conv2d_fwd_split_bnin")
+    if t0 is not None:
+        TIMER.end("conv_fwd", 2.0 * y.numel() * KH * KW * Cin, t0)
+    return y, tiles.value
+
+
+def conv2d_wgrad_split_bnin(x: torch.Tensor, dy: torch.Tensor, dw_hwio: torch.Tensor, stride: int, pad: int, ws: torch.Tensor, bn_in,
+                            stream: Optional[int] = None) -> torch.Tensor:
+    """conv2d_wgrad_split with relu(bn(x)) as the input operand; bn_in = (mean, invstd, gamma, beta)."""
+    N, H, W, Cin = x.shape
+    KH, KW, _, Cout = dw_hwio.shape
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_wgrad_split_bnin(_p(x), _p(dy), _p(dw_hwio), N, H, W, Cin, Cout, KH, KW, stride, pad, _p(bn_in[0]),
+                                                  _p(bn_in[1]), _p(bn_in[2]), _p(bn_in[3]), _p(ws), ws.numel() * ws.element_size(),
+                                                  stream or cur_stream()), "mla_conv2d_wgrad_split_bnin")
+    if t0 is not None:
+        TIMER.end("conv_wgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
+    return dw_hwio
+
+
+def conv2d_dgrad_split_bnmask(dy: torch.Tensor, wsplit: torch.Tensor, w_shape, x_shape, stride: int, pad: int, dx: torch.Tensor, bn_req,
+                              mask_gamma: torch.Tensor, mask_beta: torch.Tensor, stream: Optional[int] = None):
+    """conv2d_dgrad_split whose ReLU mask is relu(bn(bn_req.x)) > 0 -- the BatchNorm whose backward reduction the epilogue forms anyway
+    (bn_req = (x, mean, invstd, partial)).  Returns (dx, tiles)."""
+    N, H, W, Cin = x_shape
+    KH, KW, _, Cout = w_shape
+    arr, nreq = _bn_reqs([bn_req], x_shape)
+    tiles = ctypes.c_int(0)
+    t0 = TIMER.begin() if TIMER is not None else None
+    check(_lib.load().mla_conv2d_dgrad_split_bnmask(_p(dy), _p(wsplit, torch.int16), _p(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                                    ctypes.addressof(arr), nreq, ctypes.addressof(tiles), _p(mask_gamma), _p(mask_beta),
+                                                    stream or cur_stream()), "mla_conv2d_dgrad_split_bnmask")
+    if t0 is not None:
+        TIMER.end("conv_dgrad", 2.0 * dy.numel() * KH * KW * Cin, t0)
+    return dx, tiles.value
+
+
 def conv2d_stem_supported(Cin: int, Cout: int, KH: int, KW: int, stride: int, pad: int) -> bool:
     """True where the persistent split-arithmetic stem kernels apply (7x7 / 2 / 3, 1 or 3 -> 64 channels)."""
     return bool(_lib.load().mla_conv2d_stem_supported(Cin, Cout, KH, KW, stride, pad))

@@ -346,6 +346,69 @@ def test_conv_two_phase_launch(ops, case):
     assert_close(got[1][5], got[0][5], atol=2e-6 * got[0][5].abs().max().item(), name="two-phase fused dbeta")
 
 
+@pytest.mark.parametrize("case", [(3, 20, 12), (2, 56, 56), (25, 56, 56), (25, 64, 32)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_bn_fold(ops, case):
+    """relu(bn(y)) folded into the operands of the 64 -> 64 3x3 convolutions (conv2 of the layer1 blocks): forward (+ statistics), weight
+    gradient and the ReLU mask of the input gradient re-form the activation from y with bn_apply's expression -- every result is
+    BIT-IDENTICAL to the path that materialises a = relu(bn(y)) first."""
+    N, H, W = case
+    seed = sum(case) + 23
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    M = N * H * W
+    y1 = torch.randn((N, H, W, 64), device="cuda", generator=g) * 1.3 + 0.2
+    wd = torch.randn((3, 3, 64, 64), device="cuda", generator=g) * math.sqrt(2.0 / 576)
+    dyd = torch.randn((N, H, W, 64), device="cuda", generator=g)
+    gamma = torch.randn((64,), device="cuda", generator=g) * 0.3 + 1.0
+    beta = torch.randn((64,), device="cuda", generator=g) * 0.3
+    part = torch.empty(ops.bn_stats_partial_elems(M, 64), device="cuda")
+    t = ops.bn_stats_partial(y1.view(M, 64), M, 64, part)
+    mean, invstd = torch.empty(64, device="cuda"), torch.empty(64, device="cuda")
+    ops.bn_finalize(part, t, M, 64, mean, invstd, None, None)
+    bn_in = (mean, invstd, gamma, beta)
+    a1 = torch.empty_like(y1)
+    ops.bn_apply(y1, mean, invstd, gamma, beta, a1, M, 64, True)
+    wT, wS = ops.conv2d_wsplit(wd, True), ops.conv2d_wsplit(wd, False)
+    default_patch = ops.conv2d_patch()
+    tiles = (N * H * W + 255) // 256         # the patch kernel is the default where its grid uses >= 75 % of the slots of its rounds of 256 CUs
+    default_on = tiles * 4 >= ((tiles + 255) // 256) * 256 * 3
+    assert ops.conv2d_bnfold_supported(N, H, W, 64, 64, 3, 3, 1, 1) == default_on, "folded only where the patch kernel would run anyway"
+    ops.conv2d_patch(2)            # the reference launches on the same (persistent patch) kernel: another kernel sums K in another order
+    try:
+        assert ops.conv2d_bnfold_supported(N, H, W, 64, 64, 3, 3, 1, 1)
+        assert not ops.conv2d_bnfold_supported(N, H, W, 128, 128, 3, 3, 1, 1) and not ops.conv2d_bnfold_supported(N, H, W, 64, 64, 3, 3, 2, 1)
+        _bn_fold_checks(ops, N, H, W, M, y1, a1, wd, wT, wS, dyd, bn_in, mean, invstd, gamma, beta)
+    finally:
+        ops.conv2d_patch(default_patch)
+
+
+def _bn_fold_checks(ops, N, H, W, M, y1, a1, wd, wT, wS, dyd, bn_in, mean, invstd, gamma, beta):
+    # forward with statistics
+    p1 = torch.zeros(ops.conv2d_fwd_partial_elems(N, H, W, 64, 64, 3, 3, 1, 1), device="cuda")
+    p2 = torch.zeros_like(p1)
+    y_ref, t1 = ops.conv2d_fwd_split(a1, wT, wd.shape, 1, 1, bn_partial=p1)
+    y_f, t2 = ops.conv2d_fwd_split_bnin(y1, wT, wd.shape, 1, 1, bn_in, bn_partial=p2)
+    y_e, _ = ops.conv2d_fwd_split_bnin(y1, wT, wd.shape, 1, 1, bn_in)
+    torch.cuda.synchronize()
+    assert t1 == t2 and torch.equal(y_f, y_ref) and torch.equal(y_e, y_ref), "folded forward"
+    assert torch.equal(p1.view(torch.float64)[:t1 * 128], p2.view(torch.float64)[:t2 * 128]), "folded forward: statistics rows"
+    # weight gradient
+    ws = torch.empty(ops.conv2d_wgrad_split_ws_bytes(N, H, W, 64, 64, 3, 3, 1, 1) // 4 + 4, device="cuda")
+    dw_ref, dw_f = torch.empty_like(wd), torch.empty_like(wd)
+    ops.conv2d_wgrad_split(a1, dyd, dw_ref, 1, 1, ws)
+    ops.conv2d_wgrad_split_bnin(y1, dyd, dw_f, 1, 1, ws, bn_in)
+    torch.cuda.synchronize()
+    assert torch.equal(dw_f, dw_ref), "folded weight gradient"
+    # input gradient: mask relu(bn(y1)) > 0 re-formed from the BatchNorm input of the fused reduction
+    need = ops.conv2d_dgrad_bn_partial_elems(N, H, W, 64)
+    r1, r2 = torch.full((need,), float("nan"), device="cuda"), torch.full((need,), float("nan"), device="cuda")
+    dx_ref, rt1 = ops.conv2d_dgrad_split(dyd, wS, wd.shape, (N, H, W, 64), 1, 1, relu_src=a1, bn_reqs=[(y1, mean, invstd, r1)])
+    dx_f = torch.empty_like(dx_ref)
+    _, rt2 = ops.conv2d_dgrad_split_bnmask(dyd, wS, wd.shape, (N, H, W, 64), 1, 1, dx_f, (y1, mean, invstd, r2), gamma, beta)
+    torch.cuda.synchronize()
+    assert rt1 == rt2 and torch.equal(dx_f, dx_ref) and torch.equal(r1[:rt1 * 128], r2[:rt2 * 128]), "folded input-gradient mask"
+    assert (dx_ref == 0).float().mean().item() > 0.2, "the mask must actually mask"
+
+
 STEM_CASES = [
     # N, H, W, Cin: the 7x7 / 2 / 3 stem (backbone.py:79-83) on the persistent split-arithmetic kernels (stem_split.hip)
     (2, 40, 24, 1),        # audio, ragged tiles (OH x OW = 20 x 12)

@@ -346,6 +346,34 @@ def test_stream_overlap_is_bitwise_equivalent():
         assert torch.equal(x, y)
 
 
+def test_bn_fold_is_bitwise_equivalent():
+    """relu(bn1(.)) folded into conv2's operands (layer1 blocks, encoder.BN_FOLD) is the same arithmetic as the bn_apply pass: three steps give
+    bit-identical losses, parameters and running statistics with the fold on and off; the folded blocks exist."""
+    from mla_hip import encoder, ops
+    seed, B = 59, 4
+    runs = {}
+    saved, saved_patch = encoder.BN_FOLD, ops.conv2d_patch()
+    ops.conv2d_patch(2)          # both runs on the patch kernels (at these sizes the unfolded conv2 would otherwise take the gather-GEMM, which
+    try:                         # sums K in another order)
+        for fold in (True, False):
+            encoder.BN_FOLD = fold
+            model, tr, _ = build(seed, "as_intended", False, "split")
+            tr.keep_debug = False
+            for step in range(3):
+                spec, image, label = inputs(seed, step, B, (128, 64), 2, (64, 64))
+                losses = tr.train_step(spec.cuda(), image.cuda(), label.cuda(), step, 10)
+            torch.cuda.synchronize()
+            folded = sum(bool(blk["fold"]) for enc in (model.audio_net, model.visual_net) for blk in enc._ws["blocks"])
+            runs[fold] = (folded, model.audio_net.flat.cpu(), model.visual_net.flat.cpu(), model.fusion_module.fc_out.flat.cpu(),
+                          losses["loss"].cpu(), model.audio_net.running.cpu(), model.visual_net.running.cpu())
+    finally:
+        encoder.BN_FOLD = saved
+        ops.conv2d_patch(saved_patch)
+    assert runs[True][0] == 4 and runs[False][0] == 0, "layer1's two blocks of both encoders fold, nothing else does"
+    for x, y in zip(runs[True][1:], runs[False][1:]):
+        assert torch.equal(x, y)
+
+
 def test_device_feeder_delivers_batches_in_order():
     """SURVEY 8f-2 batch contract: tuples of host tensors (fp32 spec / frames, int64 labels) arrive on the device unchanged
     and in order, also when the consumer lags (slots are recycled only after the consuming step was enqueued)."""

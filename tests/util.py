@@ -51,7 +51,8 @@ def oracle_cache_from_hip(enc, params_before=None):
     cache["pool_idx"] = (oy * 2 - 1 + code // 3) * W + (ox * 2 - 1 + code % 3)
     for blk in ws["blocks"]:
         pre = blk["pre"]
-        cache[pre + ".in"], cache[pre + ".out"], cache[pre + ".a1"] = to(blk["xin"]), to(blk["out"]), to(blk["a1"])
+        a1 = enc.block_a1(blk, *((params_before[pre + ".bn1.weight"], params_before[pre + ".bn1.bias"]) if params_before else ()))
+        cache[pre + ".in"], cache[pre + ".out"], cache[pre + ".a1"] = to(blk["xin"]), to(blk["out"]), to(a1)
         cache[pre + ".bn1"] = (to(blk["y1"]),) + st(pre + ".bn1")
         cache[pre + ".bn2"] = (to(blk["y2"]),) + st(pre + ".bn2")
         if blk["ds"]:
