@@ -539,7 +539,12 @@ bool mla_patch_supported(const IGemmGeom& g, bool force) {
   const int BN = g.CO % 128 == 0 ? 128 : 64;
   const long wgs = (long)cdiv(g.M, PT_BM) * (g.CO / BN);
   const long rounds = (wgs + 255) / 256;
-  return wgs * 4 >= rounds * 256 * 3;                                        // >= 75 % of the slots of its rounds are used
+  static int min_fill = -1;                                                  // percent of the slots of its rounds that must be used
+  if (min_fill < 0) {
+    const char* e = getenv("MLA_PATCH_MIN_FILL");
+    min_fill = e ? atoi(e) : 75;
+  }
+  return wgs * 100 >= rounds * 256 * min_fill;
 }
 
 static int g_patch_persistent = -1;       // -1: $MLA_PATCH_PERSISTENT (default 1)
