@@ -139,3 +139,30 @@ def test_bgemm_rejects_descriptors_that_leave_their_buffers():
     assert call(good_a, good_b, good_c, qkv_elems, qkv_elems - D, p_elems - 1) == -1       # C one element short
     assert b"operand 2" in lib.mla_last_error()
     assert call(good_a, L4(n * 3 * D, hd, -1, 3 * D), good_c, qkv_elems, qkv_elems - D, p_elems) == -1    # negative stride
+
+
+def test_host_side_sizing_and_selection_logic():
+    """Host functions of the round-3 kernels that launch nothing: workspaces cover every kernel a shape may be routed to, the folded-BatchNorm
+    entry points are offered only for the 64 -> 64 3x3 / 1 / 1 shapes whose grid the persistent patch kernel fills, hooks answer queries."""
+    from mla_hip import _lib
+    lib = _lib.load()
+    # all-taps weight gradient on flat tiles: one full-size [9][Cin][Cout] slab per tile split (256 CUs / block pairs)
+    for (N, H, W, C) in ((64, 28, 28, 128), (192, 14, 14, 256), (64, 4, 4, 512), (3, 7, 7, 512)):
+        pairs = (C // 64) ** 2
+        splits = max(1, min((N * H * W + 63) // 64, 256 // pairs))
+        assert lib.mla_conv2d_wgrad_split_ws_bytes(N, H, W, C, C, 3, 3, 1, 1) >= splits * 9 * C * C * 4
+    # Linear weight gradient on 192 x 192 tiles: slabs + bias rows per split
+    for (M, K, N) in ((16448, 768, 2304), (16448, 3072, 768), (771, 768, 768)):
+        pairs = (K // 192) * (N // 192)
+        splits = max(1, min((M + 31) // 32, 256 // pairs))
+        assert lib.mla_linear_wgrad_split_ws_bytes(M, K, N) >= splits * (K * N + N) * 4
+    # folded BatchNorm: layer1 shapes at batch 64 yes; other channel counts / strides / under-filled grids no
+    assert lib.mla_conv2d_bnfold_supported(64, 256, 32, 64, 64, 3, 3, 1, 1) == 1
+    assert lib.mla_conv2d_bnfold_supported(192, 56, 56, 64, 64, 3, 3, 1, 1) == 1
+    assert lib.mla_conv2d_bnfold_supported(2, 56, 56, 64, 64, 3, 3, 1, 1) == 0          # 25 tiles: the gather-GEMM runs such a conv
+    assert lib.mla_conv2d_bnfold_supported(64, 128, 16, 128, 128, 3, 3, 1, 1) == 0
+    assert lib.mla_conv2d_bnfold_supported(64, 256, 32, 64, 64, 3, 3, 2, 1) == 0
+    assert lib.mla_conv2d_bnfold_supported(64, 256, 32, 64, 64, 1, 1, 1, 0) == 0
+    for hook in ("mla_conv2d_patch", "mla_conv2d_wgrad_tr", "mla_conv2d_dgrad_merge", "mla_conv2d_two_phase"):
+        assert getattr(lib, hook)(-1) in (0, 1, 2)                                       # query only
+
